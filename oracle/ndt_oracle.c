@@ -1,0 +1,766 @@
+/*
+ * ndt_oracle.c -- CPU restatement (C99) of the reference's NDT hot path.  See ndt_oracle.h:
+ * TEST INFRASTRUCTURE ONLY, PARITY UNPINNED (PCL absent; no golden vectors in the reference).
+ *
+ * Each function cites the reference call site it stands behind (paths under /root/reference)
+ * and the SURVEY.md 8a row whose PCL semantics it restates.  The 6-DoF problem is restated
+ * in its exact SE(2) reduction (SURVEY.md 8a note: every point has z = 0,
+ * include/ndt_slam/PoseEstimator.h:100, so the (z, roll, pitch) block is inert).
+ *
+ * Build: gcc -O2 -ffp-contract=off (no FMA contraction: sums must round as the scalar
+ * reference code does).
+ */
+#include "ndt_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* parameters                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Defaults: PoseEstimator.h:63-64 constructor values overridden by ndt_mapping.launch:32-36
+ * are set by the caller; here the PCL-side defaults. */
+void ndt_oracle_default_params(ndt_oracle_params *p) {
+  memset(p, 0, sizeof(*p));
+  p->resolution = 1.0f;   /* PoseEstimator.h:64 */
+  p->step_size = 0.1;     /* PoseEstimator.h:64 */
+  p->trans_eps = 0.01;    /* PoseEstimator.h:64 */
+  p->max_iter = 35;       /* PoseEstimator.h:64 */
+  p->outlier_ratio = 0.55;
+  p->min_pts = 6;
+  p->eig_mult = 0.01;
+  p->cov_unbiased = 0;
+  p->cov_init_identity = 0;
+  p->conv_ge = 0;
+  p->radius_inclusive = 0;
+  p->transform_sse = 0;
+  p->stale_h_ang = 1;
+  p->snap_thresh = 10e-5;
+  p->mt_max_iter = 10;
+  p->mt_mu = 1.e-4;
+  p->mt_nu = 0.9;
+}
+
+/* a3: Gaussian fitting constants, Magnusson 2009 eq 6.8, recomputed at the top of
+ * computeTransformation (called from src/PoseEstimator.cpp:28 ndt.align). */
+void ndt_oracle_gauss(const ndt_oracle_params *prm, double *d1, double *d2) {
+  double res = (double)prm->resolution;
+  double c1 = 10.0 * (1.0 - prm->outlier_ratio);
+  double c2 = prm->outlier_ratio / pow(res, 3);
+  double d3 = -log(c2);
+  *d1 = -log(c1 + c2) - d3;
+  *d2 = -2.0 * log((-log(c1 * exp(-0.5) + c2) - d3) / *d1);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* map (a2)                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+struct ndt_oracle_map {
+  ndt_oracle_params prm;
+  float inv_leaf;         /* 1.0f / leaf, float32 as VoxelGrid::setLeafSize computes it */
+  float leaf;
+  int min_bx, min_by, div_x, div_y;
+  size_t n_points;
+  /* dense grid */
+  int *cell_id;           /* div_x*div_y: compact id of voxels in the centroid search set, else -1 */
+  int *pt_start;          /* div_x*div_y + 1: bucket offsets of raw points (input order kept)    */
+  float *pts;             /* 2*n_points raw xy bucketed by voxel (for a7)                        */
+  /* compact cell table, ascending dense index */
+  int n_cells, n_valid;
+  int *c_idx;
+  float *c_cent;          /* 2 per cell: float32 centroid (the kd-tree point)                    */
+  double *c_mean;         /* 2 per cell                                                          */
+  double *c_icov;         /* 3 per cell: xx, xy, yy                                              */
+  int *c_npts;            /* >0 accepted, <0 rejected covariance                                 */
+  double d1, d2;
+  float r2;               /* float32 squared search radius                                       */
+};
+
+static inline const float *pt_at(const float *xy, size_t stride, size_t i) {
+  return (const float *)((const char *)xy + i * stride);
+}
+
+/* float32 voxel coordinate as VoxelGridCovariance::applyFilter computes it:
+ * static_cast<int>(floor(x * inverse_leaf_size)) with float operands. */
+static inline int vox_coord(float x, float inv_leaf) { return (int)floorf(x * inv_leaf); }
+
+void ndt_oracle_map_destroy(ndt_oracle_map *m) {
+  if (!m) return;
+  free(m->cell_id); free(m->pt_start); free(m->pts);
+  free(m->c_idx); free(m->c_cent); free(m->c_mean); free(m->c_icov); free(m->c_npts);
+  free(m);
+}
+
+/* Per-voxel statistics -> mean, regularised covariance, inverse covariance.
+ * Restates the second loop of VoxelGridCovariance::applyFilter for a z = 0 voxel
+ * (SURVEY.md 8a row a2).  sx,sy: fp64 point sums; sxx,sxy,syy: fp64 sums of products
+ * (plus the identity when cov_init_identity).  Returns 1 accepted, 0 rejected. */
+static int leaf_finalize(const ndt_oracle_params *prm, int n, double sx, double sy, double sxx,
+                         double sxy, double syy, double szz, double mean[2], double icov[3]) {
+  double dn = (double)n;
+  double mx = sx / dn, my = sy / dn;
+  mean[0] = mx; mean[1] = my;
+  icov[0] = icov[1] = icov[2] = 0.0;
+  double cxx, cxy, cyy, czz;
+  if (!prm->cov_unbiased) {
+    /* cov = (Sxx - 2 (sum mu^T)) / n + mu mu^T ; cov *= (n-1)/n */
+    cxx = (sxx - 2.0 * (sx * mx)) / dn + mx * mx;
+    cxy = (sxy - 2.0 * (sx * my)) / dn + mx * my;
+    cyy = (syy - 2.0 * (sy * my)) / dn + my * my;
+    czz = szz / dn;
+    double f = (dn - 1.0) / dn;
+    cxx *= f; cxy *= f; cyy *= f; czz *= f;
+  } else {
+    cxx = (sxx - sx * mx) / (dn - 1.0);
+    cxy = (sxy - sx * my) / (dn - 1.0);
+    cyy = (syy - sy * my) / (dn - 1.0);
+    czz = szz / (dn - 1.0);
+  }
+  /* symmetric eigen-decomposition; the z eigenpair is exactly (czz, e_z) because the
+   * covariance has an exactly zero z row/column (SURVEY.md 8a note).  2x2 block closed form. */
+  double hd = 0.5 * (cxx - cyy);
+  double tr = 0.5 * (cxx + cyy);
+  double rad = sqrt(hd * hd + cxy * cxy);
+  double l1 = tr - rad, l2 = tr + rad; /* l1 <= l2 */
+  /* eigenvector of l2 */
+  double vx, vy;
+  if (rad == 0.0) { vx = 1.0; vy = 0.0; }
+  else if (hd >= 0.0) { vx = hd + rad; vy = cxy; }
+  else { vx = cxy; vy = rad - hd; }
+  double vn = sqrt(vx * vx + vy * vy);
+  if (vn == 0.0) { vx = 1.0; vy = 0.0; } else { vx /= vn; vy /= vn; }
+  /* v2 = (vx,vy) for l2; v1 = (-vy,vx) for l1 */
+  /* ascending sort of {l1, l2, czz} as SelfAdjointEigenSolver returns them */
+  double ev[3]; int kind[3]; /* kind: 0 = l1, 1 = l2, 2 = z */
+  ev[0] = l1; kind[0] = 0; ev[1] = l2; kind[1] = 1; ev[2] = czz; kind[2] = 2;
+  for (int a = 1; a < 3; ++a) {         /* insertion sort, z sorts first among equals */
+    double e = ev[a]; int k = kind[a]; int b = a - 1;
+    while (b >= 0 && (ev[b] > e || (ev[b] == e && k == 2))) { ev[b + 1] = ev[b]; kind[b + 1] = kind[b]; --b; }
+    ev[b + 1] = e; kind[b + 1] = k;
+  }
+  if (ev[0] < 0 || ev[1] < 0 || ev[2] <= 0) return 0; /* rejected: stays searchable, icov = 0 */
+  double thr = prm->eig_mult * ev[2];
+  int rebuilt = 0;
+  if (ev[0] < thr) {                      /* nested inflation quirk kept */
+    ev[0] = thr;
+    if (ev[1] < thr) ev[1] = thr;
+    rebuilt = 1;
+  }
+  double n1 = l1, n2 = l2;
+  for (int a = 0; a < 3; ++a) { if (kind[a] == 0) n1 = ev[a]; else if (kind[a] == 1) n2 = ev[a]; }
+  if (rebuilt) {                          /* cov = V diag V^-1 (V orthonormal) */
+    cxx = n1 * (vy * vy) + n2 * (vx * vx);
+    cxy = -n1 * (vx * vy) + n2 * (vx * vy);
+    cyy = n1 * (vx * vx) + n2 * (vy * vy);
+  }
+  double det = cxx * cyy - cxy * cxy;
+  icov[0] = cyy / det;
+  icov[1] = -cxy / det;
+  icov[2] = cxx / det;
+  /* icov inf check: voxel flagged rejected but keeps the inf entries (PCL leaves icov_ as is) */
+  for (int a = 0; a < 3; ++a)
+    if (icov[a] == (double)INFINITY || icov[a] == -(double)INFINITY) return -1;
+  return 1;
+}
+
+ndt_oracle_map *ndt_oracle_map_build(const float *xy, size_t n, size_t stride,
+                                     const ndt_oracle_params *prm) {
+  if (!xy || n == 0 || !prm || !(prm->resolution > 0)) return NULL;
+  ndt_oracle_map *m = (ndt_oracle_map *)calloc(1, sizeof(*m));
+  m->prm = *prm;
+  m->leaf = prm->resolution;
+  m->inv_leaf = 1.0f / prm->resolution;
+  m->n_points = n;
+  ndt_oracle_gauss(prm, &m->d1, &m->d2);
+  m->r2 = (float)((double)prm->resolution * (double)prm->resolution);
+
+  /* getMinMax3D in float, then min_b = floor(min * inv_leaf) */
+  float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+  size_t nfin = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float *p = pt_at(xy, stride, i);
+    if (!isfinite(p[0]) || !isfinite(p[1])) continue;
+    if (p[0] < mnx) mnx = p[0];
+    if (p[0] > mxx) mxx = p[0];
+    if (p[1] < mny) mny = p[1];
+    if (p[1] > mxy) mxy = p[1];
+    ++nfin;
+  }
+  if (nfin == 0) { free(m); return NULL; }
+  m->min_bx = (int)floorf(mnx * m->inv_leaf);
+  m->min_by = (int)floorf(mny * m->inv_leaf);
+  int max_bx = (int)floorf(mxx * m->inv_leaf);
+  int max_by = (int)floorf(mxy * m->inv_leaf);
+  long long dx = (long long)max_bx - m->min_bx + 1, dy = (long long)max_by - m->min_by + 1;
+  if (dx * dy > (1LL << 28)) { free(m); return NULL; } /* PCL: "leaf size too small", no grid */
+  m->div_x = (int)dx; m->div_y = (int)dy;
+  size_t ng = (size_t)(dx * dy);
+
+  /* bucket raw points by voxel keeping input order (counting sort is stable) */
+  m->pt_start = (int *)calloc(ng + 1, sizeof(int));
+  int *vox = (int *)malloc(n * sizeof(int));
+  for (size_t i = 0; i < n; ++i) {
+    const float *p = pt_at(xy, stride, i);
+    if (!isfinite(p[0]) || !isfinite(p[1])) { vox[i] = -1; continue; }
+    int ix = vox_coord(p[0], m->inv_leaf) - m->min_bx;
+    int iy = vox_coord(p[1], m->inv_leaf) - m->min_by;
+    vox[i] = iy * m->div_x + ix;
+    m->pt_start[vox[i] + 1]++;
+  }
+  for (size_t g = 0; g < ng; ++g) m->pt_start[g + 1] += m->pt_start[g];
+  m->pts = (float *)malloc(2 * (nfin ? nfin : 1) * sizeof(float));
+  int *fill = (int *)malloc(ng * sizeof(int));
+  memcpy(fill, m->pt_start, ng * sizeof(int));
+  for (size_t i = 0; i < n; ++i) {
+    if (vox[i] < 0) continue;
+    const float *p = pt_at(xy, stride, i);
+    int s = fill[vox[i]]++;
+    m->pts[2 * s] = p[0]; m->pts[2 * s + 1] = p[1];
+  }
+  free(fill); free(vox);
+
+  /* per-voxel statistics, sequential in input order (float32 centroid, fp64 mean/cov) */
+  m->cell_id = (int *)malloc(ng * sizeof(int));
+  int nc = 0;
+  for (size_t g = 0; g < ng; ++g) {
+    int cnt = m->pt_start[g + 1] - m->pt_start[g];
+    if (cnt >= prm->min_pts) m->cell_id[g] = nc++; else m->cell_id[g] = -1;
+  }
+  m->n_cells = nc;
+  m->c_idx = (int *)malloc((nc ? nc : 1) * sizeof(int));
+  m->c_cent = (float *)malloc(2 * (nc ? nc : 1) * sizeof(float));
+  m->c_mean = (double *)malloc(2 * (nc ? nc : 1) * sizeof(double));
+  m->c_icov = (double *)malloc(3 * (nc ? nc : 1) * sizeof(double));
+  m->c_npts = (int *)malloc((nc ? nc : 1) * sizeof(int));
+  m->n_valid = 0;
+  for (size_t g = 0; g < ng; ++g) {
+    int c = m->cell_id[g];
+    if (c < 0) continue;
+    int s0 = m->pt_start[g], s1 = m->pt_start[g + 1];
+    float fx = 0.f, fy = 0.f;
+    double sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0, szz = 0;
+    if (prm->cov_init_identity) { sxx = 1.0; syy = 1.0; szz = 1.0; }
+    for (int s = s0; s < s1; ++s) {
+      float x = m->pts[2 * s], y = m->pts[2 * s + 1];
+      fx += x; fy += y;                       /* float32 centroid accumulator */
+      double X = (double)x, Y = (double)y;
+      sx += X; sy += Y;
+      sxx += X * X; sxy += X * Y; syy += Y * Y;
+    }
+    int cnt = s1 - s0;
+    m->c_idx[c] = (int)g;
+    m->c_cent[2 * c] = fx / (float)cnt;
+    m->c_cent[2 * c + 1] = fy / (float)cnt;
+    int ok = leaf_finalize(prm, cnt, sx, sy, sxx, sxy, syy, szz, &m->c_mean[2 * c], &m->c_icov[3 * c]);
+    m->c_npts[c] = (ok > 0) ? cnt : -cnt;
+    if (ok > 0) m->n_valid++;
+  }
+  return m;
+}
+
+void ndt_oracle_map_info_get(const ndt_oracle_map *m, ndt_oracle_map_info *o) {
+  o->min_bx = m->min_bx; o->min_by = m->min_by; o->div_x = m->div_x; o->div_y = m->div_y;
+  o->n_cells = m->n_cells; o->n_valid = m->n_valid; o->n_points = m->n_points;
+}
+
+void ndt_oracle_map_export(const ndt_oracle_map *m, int *cell_idx, float *cent, double *mean,
+                           double *icov, int *npts) {
+  memcpy(cell_idx, m->c_idx, m->n_cells * sizeof(int));
+  memcpy(cent, m->c_cent, 2 * m->n_cells * sizeof(float));
+  memcpy(mean, m->c_mean, 2 * m->n_cells * sizeof(double));
+  memcpy(icov, m->c_icov, 3 * m->n_cells * sizeof(double));
+  memcpy(npts, m->c_npts, m->n_cells * sizeof(int));
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a4: pcl::transformPointCloud with the float32 matrix [[c,-s,0,tx],[s,c,0,ty],...]           */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct { float c, s, tx, ty; } tf32;
+
+/* float32 matrix from the fp64 parameter vector, as computeStepLengthMT builds
+ * final_transformation_ = Translation3f(float(p0),float(p1),0) * AngleAxisf(float(p2), Z).
+ * std::cos/std::sin on a float argument are modelled as correctly rounded. */
+static tf32 tf_from_p(const double p[3]) {
+  tf32 t;
+  float yaw = (float)p[2];
+  t.c = (float)cos((double)yaw);
+  t.s = (float)sin((double)yaw);
+  t.tx = (float)p[0];
+  t.ty = (float)p[1];
+  return t;
+}
+
+static inline void tf_apply(const ndt_oracle_params *prm, tf32 t, float x, float y, float *ox,
+                            float *oy) {
+  float ms = -t.s;
+  if (!prm->transform_sse) {
+    float a = t.c * x, b = ms * y; float r = a + b; *ox = r + t.tx;
+    float c = t.s * x, d = t.c * y; float q = c + d; *oy = q + t.ty;
+  } else {
+    float a = t.c * x, b = ms * y; float r = b + t.tx; *ox = a + r;
+    float c = t.s * x, d = t.c * y; float q = d + t.ty; *oy = c + q;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a5: computeDerivatives / updateDerivatives / computeHessian (HOT LOOP A)                    */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct { double cj, sj, ch, sh; } angle_terms;
+
+/* computeAngleDerivatives: small-angle snap in J and h only. */
+static void angle_cs(const ndt_oracle_params *prm, double yaw, double *c, double *s) {
+  if (fabs(yaw) < prm->snap_thresh) { *c = 1.0; *s = 0.0; }
+  else { *c = cos(yaw); *s = sin(yaw); }
+}
+
+/* One pass over the scan.  trans: 2n transformed float32 coordinates; src: untransformed.
+ * mode 0: score+gradient ; 1: score+gradient+Hessian ; 2: Hessian only. */
+static double eval_pass(const ndt_oracle_map *m, const float *src, size_t n, size_t stride,
+                        const float *trans, angle_terms at, int mode, double g[3], double H[6],
+                        double *pairs) {
+  const ndt_oracle_params *prm = &m->prm;
+  const double d1 = m->d1, d2 = m->d2;
+  double score = 0.0;
+  double gg[3] = {0, 0, 0}, hh[6] = {0, 0, 0, 0, 0, 0};
+  double npairs = 0;
+  for (size_t i = 0; i < n; ++i) {
+    float xt = trans[2 * i], yt = trans[2 * i + 1];
+    if (!isfinite(xt) || !isfinite(yt)) continue;
+    int ix = vox_coord(xt, m->inv_leaf) - m->min_bx;
+    int iy = vox_coord(yt, m->inv_leaf) - m->min_by;
+    /* radius search over voxel centroids, r = resolution: subset of the 3x3 neighbourhood */
+    int cand[9]; float cd2[9]; int nc = 0;
+    for (int dy = -1; dy <= 1; ++dy) {
+      int yy = iy + dy; if (yy < 0 || yy >= m->div_y) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        int xx = ix + dx; if (xx < 0 || xx >= m->div_x) continue;
+        int c = m->cell_id[(size_t)yy * m->div_x + xx];
+        if (c < 0) continue;
+        float ex = xt - m->c_cent[2 * c], ey = yt - m->c_cent[2 * c + 1];
+        float dd = 0.f; dd += ex * ex; dd += ey * ey;   /* flann::L2_Simple<float> */
+        int in = prm->radius_inclusive ? (dd <= m->r2) : (dd < m->r2);
+        if (!in) continue;
+        int k = nc++;                                   /* keep sorted by (distance, id) */
+        while (k > 0 && (cd2[k - 1] > dd || (cd2[k - 1] == dd && cand[k - 1] > c))) {
+          cd2[k] = cd2[k - 1]; cand[k] = cand[k - 1]; --k;
+        }
+        cd2[k] = dd; cand[k] = c;
+      }
+    }
+    if (nc == 0) continue;
+    const float *sp = pt_at(src, stride, i);
+    double x = (double)sp[0], y = (double)sp[1];
+    /* computePointDerivatives: yaw column of J_E and the (yaw,yaw) block of H_E */
+    double jx = x * (-at.sj) + y * (-at.cj);
+    double jy = x * at.cj + y * (-at.sj);
+    double hx = x * (-at.ch) + y * at.sh;
+    double hy = x * (-at.sh) + y * (-at.ch);
+    for (int k = 0; k < nc; ++k) {
+      int c = cand[k];
+      npairs += 1.0;
+      double q0 = (double)xt - m->c_mean[2 * c], q1 = (double)yt - m->c_mean[2 * c + 1];
+      double i00 = m->c_icov[3 * c], i01 = m->c_icov[3 * c + 1], i11 = m->c_icov[3 * c + 2];
+      double u0 = i00 * q0 + i01 * q1, u1 = i01 * q0 + i11 * q1;
+      double e = exp(-d2 * (q0 * u0 + q1 * u1) / 2);
+      double score_inc = -d1 * e;
+      e = d2 * e;
+      if (e > 1 || e < 0 || e != e) continue;           /* updateDerivatives error check */
+      e *= d1;
+      if (mode != 2) score += score_inc;
+      /* Sigma^-1 * dT/dp_i for i = tx, ty, yaw */
+      double ctx0 = i00, ctx1 = i01, cty0 = i01, cty1 = i11;
+      double ctt0 = i00 * jx + i01 * jy, ctt1 = i01 * jx + i11 * jy;
+      double ax = q0 * ctx0 + q1 * ctx1;
+      double ay = q0 * cty0 + q1 * cty1;
+      double atq = q0 * ctt0 + q1 * ctt1;
+      if (mode != 2) { gg[0] += ax * e; gg[1] += ay * e; gg[2] += atq * e; }
+      if (mode != 0) {
+        double qh = q0 * (i00 * hx + i01 * hy) + q1 * (i01 * hx + i11 * hy);
+        hh[0] += e * (-d2 * ax * ax + ctx0);                         /* xx */
+        hh[1] += e * (-d2 * ax * ay + ctx1);                         /* xy */
+        hh[2] += e * (-d2 * ax * atq + (jx * ctx0 + jy * ctx1));     /* xt */
+        hh[3] += e * (-d2 * ay * ay + cty1);                         /* yy */
+        hh[4] += e * (-d2 * ay * atq + (jx * cty0 + jy * cty1));     /* yt */
+        hh[5] += e * (-d2 * atq * atq + qh + (jx * ctt0 + jy * ctt1)); /* tt */
+      }
+    }
+  }
+  if (mode != 2 && g) { g[0] = gg[0]; g[1] = gg[1]; g[2] = gg[2]; }
+  if (mode != 0 && H) memcpy(H, hh, sizeof(hh));
+  if (mode == 0 && H) memset(H, 0, 6 * sizeof(double));
+  if (pairs) *pairs += npairs;
+  return score;
+}
+
+static void transform_scan(const ndt_oracle_params *prm, const float *src, size_t n, size_t stride,
+                           tf32 t, float *out) {
+  for (size_t i = 0; i < n; ++i) {
+    const float *p = pt_at(src, stride, i);
+    tf_apply(prm, t, p[0], p[1], &out[2 * i], &out[2 * i + 1]);
+  }
+}
+
+double ndt_oracle_eval_at(const ndt_oracle_map *m, const float *scan, size_t n, size_t stride,
+                          const double p[3], double g[3], double H[9], double *pairs_out) {
+  float *tr = (float *)malloc(2 * (n ? n : 1) * sizeof(float));
+  transform_scan(&m->prm, scan, n, stride, tf_from_p(p), tr);
+  angle_terms at; angle_cs(&m->prm, p[2], &at.cj, &at.sj); at.ch = at.cj; at.sh = at.sj;
+  double H6[6], pr = 0;
+  double s = eval_pass(m, scan, n, stride, tr, at, 1, g, H6, &pr);
+  if (H) { H[0] = H6[0]; H[1] = H[3] = H6[1]; H[2] = H[6] = H6[2]; H[4] = H6[3]; H[5] = H[7] = H6[4]; H[8] = H6[5]; }
+  if (pairs_out) *pairs_out = pr;
+  free(tr);
+  return s;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a6: Newton step + More-Thuente line search                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Symmetric 3x3 solve by cyclic Jacobi eigen-decomposition with pseudo-inverse thresholding.
+ * Stands in for PCL's JacobiSVD<6x6>(H).solve(-g): for a symmetric matrix the SVD is the
+ * eigen-decomposition up to signs and the 6x6 is block diagonal (SURVEY.md 8a note). */
+void ndt_oracle_solve3(const double Hin[9], const double b[3], double x[3]) {
+  double A[3][3], V[3][3];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { A[i][j] = 0.5 * (Hin[3 * i + j] + Hin[3 * j + i]); V[i][j] = (i == j); }
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) if (A[i][j] != A[i][j]) { x[0] = x[1] = x[2] = NAN; return; }
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    if (off == 0.0) break;
+    for (int p = 0; p < 2; ++p) for (int q = p + 1; q < 3; ++q) {
+      double apq = A[p][q];
+      if (apq == 0.0) continue;
+      double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+      double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+      double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+      double app = A[p][p], aqq = A[q][q];
+      A[p][p] = app - t * apq; A[q][q] = aqq + t * apq; A[p][q] = A[q][p] = 0.0;
+      int r = 3 - p - q;
+      double arp = A[r][p], arq = A[r][q];
+      A[r][p] = A[p][r] = c * arp - s * arq;
+      A[r][q] = A[q][r] = s * arp + c * arq;
+      for (int k = 0; k < 3; ++k) {
+        double vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+      }
+    }
+  }
+  double lmax = fmax(fabs(A[0][0]), fmax(fabs(A[1][1]), fabs(A[2][2])));
+  double thr = lmax * (6.0 * DBL_EPSILON);   /* JacobiSVD default threshold: diagSize * eps */
+  x[0] = x[1] = x[2] = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    double l = A[k][k];
+    if (!(fabs(l) > thr) || fabs(l) < DBL_MIN) continue;
+    double proj = (V[0][k] * b[0] + V[1][k] * b[1] + V[2][k] * b[2]) / l;
+    x[0] += V[0][k] * proj; x[1] += V[1][k] * proj; x[2] += V[2][k] * proj;
+  }
+}
+
+/* trialValueSelectionMT: More-Thuente trial value, cases 1-4 with the Sun & Yuan
+ * cubic/quadratic/secant minimisers and the 0.66 safeguard. */
+double ndt_oracle_mt_trial(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u,
+                           double a_t, double f_t, double g_t) {
+  if (f_t > f_l) {                                          /* case 1 */
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+    if (fabs(a_c - a_l) < fabs(a_q - a_l)) return a_c;
+    return 0.5 * (a_q + a_c);
+  } else if (g_t * g_l < 0) {                               /* case 2 */
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    if (fabs(a_c - a_t) >= fabs(a_s - a_t)) return a_c;
+    return a_s;
+  } else if (fabs(g_t) <= fabs(g_l)) {                      /* case 3 */
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    double a_n = (fabs(a_c - a_t) < fabs(a_s - a_t)) ? a_c : a_s;
+    double lim = a_t + 0.66 * (a_u - a_t);
+    if (a_t > a_l) return (a_n < lim) ? a_n : lim;          /* std::min(lim, a_n) */
+    return (lim < a_n) ? a_n : lim;                         /* std::max(lim, a_n) */
+  } else {                                                  /* case 4 */
+    double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
+    double w = sqrt(z * z - g_t * g_u);
+    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+  }
+}
+
+/* updateIntervalMT: cases U1-U3 / a-c; returns 1 when the interval has converged. */
+int ndt_oracle_mt_update(double *a_l, double *f_l, double *g_l, double *a_u, double *f_u,
+                         double *g_u, double a_t, double f_t, double g_t) {
+  if (f_t > *f_l) { *a_u = a_t; *f_u = f_t; *g_u = g_t; return 0; }
+  if (g_t * (*a_l - a_t) > 0) { *a_l = a_t; *f_l = f_t; *g_l = g_t; return 0; }
+  if (g_t * (*a_l - a_t) < 0) {
+    *a_u = *a_l; *f_u = *f_l; *g_u = *g_l;
+    *a_l = a_t; *f_l = f_t; *g_l = g_t; return 0;
+  }
+  return 1;
+}
+
+typedef struct {
+  const ndt_oracle_map *m;
+  const float *scan; size_t n, stride;
+  float *trans;
+  tf32 T;                 /* final_transformation_ */
+  angle_terms at;         /* j_ang (cj,sj) and h_ang (ch,sh) member state */
+  int evals, ref_evals;
+  double pairs;
+  double *trace; int trace_cap, trace_n;
+} align_ctx;
+
+static void trace_push(align_ctx *cx, double a_t, double score, const double g[3], const double p[3]) {
+  if (!cx->trace || cx->trace_n >= cx->trace_cap) { cx->trace_n++; return; }
+  double *t = cx->trace + 8 * (size_t)cx->trace_n++;
+  t[0] = a_t; t[1] = score; t[2] = g[0]; t[3] = g[1]; t[4] = g[2]; t[5] = p[0]; t[6] = p[1]; t[7] = p[2];
+}
+
+/* computeDerivatives(score_gradient, hessian, trans_cloud, p, compute_hessian) */
+static double derivatives(align_ctx *cx, const double p[3], int with_hessian, double g[3], double H[6]) {
+  angle_cs(&cx->m->prm, p[2], &cx->at.cj, &cx->at.sj);
+  if (with_hessian || !cx->m->prm.stale_h_ang) { cx->at.ch = cx->at.cj; cx->at.sh = cx->at.sj; }
+  cx->evals++; cx->ref_evals++;
+  return eval_pass(cx->m, cx->scan, cx->n, cx->stride, cx->trans, cx->at, with_hessian ? 1 : 0, g, H, &cx->pairs);
+}
+
+/* computeStepLengthMT */
+static double step_length_mt(align_ctx *cx, const double x[3], double dir[3], double step_init,
+                             double step_max, double step_min, double *score, double g[3], double H[6]) {
+  const ndt_oracle_params *prm = &cx->m->prm;
+  double phi_0 = -(*score);
+  double d_phi_0 = -(g[0] * dir[0] + g[1] * dir[1] + g[2] * dir[2]);
+  if (d_phi_0 >= 0) {
+    if (d_phi_0 == 0) return 0;
+    d_phi_0 *= -1; dir[0] *= -1; dir[1] *= -1; dir[2] *= -1;
+  }
+  const double mu = prm->mt_mu, nu = prm->mt_nu;
+  int step_iterations = 0;
+  double a_l = 0, a_u = 0;
+  double f_l = phi_0 - phi_0 - mu * d_phi_0 * a_l;   /* auxilaryFunction_PsiMT(a_l, phi_0, ...) */
+  double g_l = d_phi_0 - mu * d_phi_0;               /* auxilaryFunction_dPsiMT               */
+  double f_u = phi_0 - phi_0 - mu * d_phi_0 * a_u;
+  double g_u = d_phi_0 - mu * d_phi_0;
+  int interval_converged = (step_max - step_min) < 0, open_interval = 1;
+  double a_t = step_init;
+  a_t = (step_max < a_t) ? step_max : a_t;           /* std::min(a_t, step_max) */
+  a_t = (a_t < step_min) ? step_min : a_t;           /* std::max(a_t, step_min) */
+  double x_t[3] = {x[0] + dir[0] * a_t, x[1] + dir[1] * a_t, x[2] + dir[2] * a_t};
+  cx->T = tf_from_p(x_t);
+  transform_scan(prm, cx->scan, cx->n, cx->stride, cx->T, cx->trans);
+  *score = derivatives(cx, x_t, 1, g, H);
+  trace_push(cx, a_t, *score, g, x_t);
+  double phi_t = -(*score);
+  double d_phi_t = -(g[0] * dir[0] + g[1] * dir[1] + g[2] * dir[2]);
+  double psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t;
+  double d_psi_t = d_phi_t - mu * d_phi_0;
+  while (!interval_converged && step_iterations < prm->mt_max_iter &&
+         !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+    if (open_interval) a_t = ndt_oracle_mt_trial(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
+    else               a_t = ndt_oracle_mt_trial(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
+    a_t = (step_max < a_t) ? step_max : a_t;
+    a_t = (a_t < step_min) ? step_min : a_t;
+    x_t[0] = x[0] + dir[0] * a_t; x_t[1] = x[1] + dir[1] * a_t; x_t[2] = x[2] + dir[2] * a_t;
+    cx->T = tf_from_p(x_t);
+    transform_scan(prm, cx->scan, cx->n, cx->stride, cx->T, cx->trans);
+    *score = derivatives(cx, x_t, 0, g, H);
+    trace_push(cx, a_t, *score, g, x_t);
+    phi_t = -(*score);
+    d_phi_t = -(g[0] * dir[0] + g[1] * dir[1] + g[2] * dir[2]);
+    psi_t = phi_t - phi_0 - mu * d_phi_0 * a_t;
+    d_psi_t = d_phi_t - mu * d_phi_0;
+    if (open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+      open_interval = 0;
+      f_l = f_l + phi_0 - mu * d_phi_0 * a_l; g_l = g_l + mu * d_phi_0;
+      f_u = f_u + phi_0 - mu * d_phi_0 * a_u; g_u = g_u + mu * d_phi_0;
+    }
+    if (open_interval) interval_converged = ndt_oracle_mt_update(&a_l, &f_l, &g_l, &a_u, &f_u, &g_u, a_t, psi_t, d_psi_t);
+    else               interval_converged = ndt_oracle_mt_update(&a_l, &f_l, &g_l, &a_u, &f_u, &g_u, a_t, phi_t, d_phi_t);
+    step_iterations++;
+  }
+  if (step_iterations) {      /* computeHessian(hessian, trans_cloud, x_t): Hessian-only pass */
+    cx->evals++; cx->ref_evals++;
+    eval_pass(cx->m, cx->scan, cx->n, cx->stride, cx->trans, cx->at, 2, NULL, H, &cx->pairs);
+  }
+  return a_t;
+}
+
+/* a9: src/PoseEstimator.cpp:31-35 -- std::asin/std::acos on the float32 matrix entries
+ * (float overloads, modelled as correctly rounded), four sign branches kept verbatim in intent. */
+double ndt_oracle_yaw_from_T(float T00, float T10) {
+  double theta;
+  if (T00 > 0 && T10 > 0) theta = (double)(float)asin((double)T10);
+  else if (T00 > 0 && T10 < 0) theta = (double)(float)asin((double)T10);
+  else if (T00 < 0 && T10 > 0) theta = (double)(float)acos((double)T00);
+  else theta = (double)(float)acos((double)T00) * (-1.0);
+  return theta;
+}
+
+/* a7: Registration::getFitnessScore() -- exact 1-NN over ALL raw target points via ring
+ * search on the voxel buckets; float32 squared distances, fp64 mean. */
+static double fitness_pass(const ndt_oracle_map *m, const float *scan, size_t n, size_t stride, tf32 T) {
+  double sum = 0; long nr = 0;
+  const double L = (double)m->leaf;
+  for (size_t i = 0; i < n; ++i) {
+    const float *p = pt_at(scan, stride, i);
+    float qx, qy; tf_apply(&m->prm, T, p[0], p[1], &qx, &qy);
+    if (!isfinite(qx) || !isfinite(qy)) continue;
+    int cx = vox_coord(qx, m->inv_leaf) - m->min_bx, cy = vox_coord(qy, m->inv_leaf) - m->min_by;
+    if (cx < 0) cx = 0; if (cx >= m->div_x) cx = m->div_x - 1;
+    if (cy < 0) cy = 0; if (cy >= m->div_y) cy = m->div_y - 1;
+    float best = INFINITY;
+    int rmax = (m->div_x > m->div_y ? m->div_x : m->div_y);
+    for (int r = 0; r <= rmax; ++r) {
+      int y0 = cy - r, y1 = cy + r, x0 = cx - r, x1 = cx + r;
+      for (int yy = y0; yy <= y1; ++yy) {
+        if (yy < 0 || yy >= m->div_y) continue;
+        int stepx = (yy == y0 || yy == y1) ? 1 : (x1 - x0 > 0 ? x1 - x0 : 1);
+        for (int xx = x0; xx <= x1; xx += stepx) {
+          if (xx < 0 || xx >= m->div_x) continue;
+          size_t g = (size_t)yy * m->div_x + xx;
+          for (int s = m->pt_start[g]; s < m->pt_start[g + 1]; ++s) {
+            float ex = qx - m->pts[2 * s], ey = qy - m->pts[2 * s + 1];
+            float dd = 0.f; dd += ex * ex; dd += ey * ey;
+            if (dd < best) best = dd;
+          }
+        }
+      }
+      /* every unvisited point is farther than r*L from the query */
+      double bound = (double)r * L * 0.999;
+      if ((double)best <= bound * bound) break;
+    }
+    if (best < INFINITY) { sum += (double)best; nr++; }
+  }
+  return nr > 0 ? sum / (double)nr : DBL_MAX;
+}
+
+double ndt_oracle_fitness(const ndt_oracle_map *m, const float *scan, size_t n, size_t stride,
+                          float c, float s, float tx, float ty) {
+  tf32 T = {c, s, tx, ty};
+  return fitness_pass(m, scan, n, stride, T);
+}
+
+/* src/PoseEstimator.cpp:17-64 with the source cloud already filtered (a1 upstream). */
+int ndt_oracle_align(const ndt_oracle_map *m, const float *scan, size_t n, size_t stride,
+                     const double init[3], ndt_oracle_result *res, double *trace, int trace_cap) {
+  memset(res, 0, sizeof(*res));
+  if (!m || !scan || n == 0) { res->status = -1; res->fitness = DBL_MAX; return -1; }
+  const ndt_oracle_params *prm = &m->prm;
+  align_ctx cx; memset(&cx, 0, sizeof(cx));
+  cx.m = m; cx.scan = scan; cx.n = n; cx.stride = stride;
+  cx.trans = (float *)malloc(2 * n * sizeof(float));
+  cx.trace = trace; cx.trace_cap = trace_cap;
+
+  /* src/PoseEstimator.cpp:22-24: init_guess = Translation3f(tx,ty,0) * AngleAxisf(yaw, Z) */
+  double pinit[3] = {init[0], init[1], init[2]};
+  cx.T = tf_from_p(pinit);
+  /* computeTransformation prologue: p = (translation, eulerAngles(0,1,2)) of the float matrix;
+   * for a pure-Z rotation eulerAngles gives (-0, 0, atan2f(s, c))
+   * (include/Eigen/src/Geometry/EulerAngles.h:87-107). */
+  double p[3] = {(double)cx.T.tx, (double)cx.T.ty, (double)(float)atan2((double)cx.T.s, (double)cx.T.c)};
+  transform_scan(prm, scan, n, stride, cx.T, cx.trans);   /* transformPointCloud(output, output, guess) */
+
+  double g[3], H[6], score;
+  score = derivatives(&cx, p, 1, g, H);
+  trace_push(&cx, 0.0, score, g, p);
+
+  int converged = 0, iters = 0, nan_exit = 0;
+  while (!converged) {
+    double Hf[9] = {H[0], H[1], H[2], H[1], H[3], H[4], H[2], H[4], H[5]};
+    double mg[3] = {-g[0], -g[1], -g[2]}, dp[3];
+    ndt_oracle_solve3(Hf, mg, dp);
+    double nrm = sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]);
+    if (nrm == 0 || nrm != nrm) { converged = (nrm == nrm); nan_exit = 1; break; }
+    dp[0] /= nrm; dp[1] /= nrm; dp[2] /= nrm;
+    double a = step_length_mt(&cx, p, dp, nrm, prm->step_size, prm->trans_eps / 2, &score, g, H);
+    dp[0] *= a; dp[1] *= a; dp[2] *= a;
+    p[0] += dp[0]; p[1] += dp[1]; p[2] += dp[2];
+    int over = prm->conv_ge ? (iters >= prm->max_iter) : (iters > prm->max_iter);
+    if (over || (iters && (fabs(a) < prm->trans_eps))) converged = 1;
+    iters++;
+  }
+  (void)nan_exit;
+  res->iters = iters;
+  res->converged = converged;
+  res->score = score;
+  res->trans_prob = score / (double)n;
+  res->p[0] = p[0]; res->p[1] = p[1]; res->p[2] = p[2];
+  res->T00 = cx.T.c; res->T10 = cx.T.s; res->T03 = cx.T.tx; res->T13 = cx.T.ty;
+  /* src/PoseEstimator.cpp:29-36 */
+  res->pose[0] = (double)cx.T.tx; res->pose[1] = (double)cx.T.ty;
+  res->pose[2] = ndt_oracle_yaw_from_T(cx.T.c, cx.T.s);
+  /* src/PoseEstimator.cpp:43 */
+  res->fitness = fitness_pass(m, scan, n, stride, cx.T);
+  /* src/PoseEstimator.cpp:53-56: getHessian -> computeHessian on the output cloud.  It re-uses
+   * the member angle terms, so it reproduces the last Hessian of align() bit for bit; the
+   * pass is executed here as the reference executes it. */
+  double H8[6];
+  cx.evals++; cx.ref_evals++;
+  eval_pass(m, scan, n, stride, cx.trans, cx.at, 2, NULL, H8, &cx.pairs);
+  res->H[0] = H8[0]; res->H[1] = res->H[3] = H8[1]; res->H[2] = res->H[6] = H8[2];
+  res->H[4] = H8[3]; res->H[5] = res->H[7] = H8[4]; res->H[8] = H8[5];
+  res->evals = cx.evals; res->ref_evals = cx.ref_evals;
+  res->pad_ = cx.trace_n;   /* number of trace rows (derivative passes with a gradient) */
+  res->kbar = cx.pairs / ((double)cx.evals * (double)n);
+  res->status = 0;
+  free(cx.trans);
+  return 0;
+}
+
+int ndt_oracle_align_batch(const ndt_oracle_map *m, const float *scans, const uint64_t *off, int B,
+                           const double *inits, ndt_oracle_result *res, int nthreads) {
+  int rc = 0;
+#ifdef _OPENMP
+  if (nthreads > 1) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1) if (nthreads > 1)
+#endif
+  for (int b = 0; b < B; ++b) {
+    int r = ndt_oracle_align(m, scans + 2 * off[b], (size_t)(off[b + 1] - off[b]), 2 * sizeof(float),
+                             inits + 3 * b, &res[b], NULL, 0);
+    if (r) rc = r;
+  }
+  (void)nthreads;
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* a1: pcl::ApproximateVoxelGrid::filter, z = 0 cloud (src/PoseEstimator.cpp:6-10)             */
+/* ------------------------------------------------------------------------------------------ */
+size_t ndt_oracle_approx_voxel_filter(const float *xy, size_t n, size_t stride, float leaf,
+                                      float *out) {
+  enum { HIST = 512 };
+  struct he { int ix, iy, iz, count; float cx, cy; } hist[HIST];
+  memset(hist, 0, sizeof(hist));
+  float inv = 1.0f / leaf;
+  size_t op = 0;
+  for (size_t i = 0; i < n; ++i) {
+    const float *p = pt_at(xy, stride, i);
+    int ix = (int)floorf(p[0] * inv), iy = (int)floorf(p[1] * inv), iz = (int)floorf(0.0f * inv);
+    unsigned h = (unsigned)((ix * 7171 + iy * 3079 + iz * 4231) & (HIST - 1));
+    struct he *e = &hist[h];
+    if (e->count && (ix != e->ix || iy != e->iy || iz != e->iz)) {
+      out[2 * op] = e->cx / (float)e->count; out[2 * op + 1] = e->cy / (float)e->count; ++op;
+      e->count = 0; e->cx = 0.f; e->cy = 0.f;
+    }
+    e->ix = ix; e->iy = iy; e->iz = iz; e->count++;
+    e->cx += p[0]; e->cy += p[1];
+  }
+  for (int h = 0; h < HIST; ++h) {
+    struct he *e = &hist[h];
+    if (e->count) { out[2 * op] = e->cx / (float)e->count; out[2 * op + 1] = e->cy / (float)e->count; ++op; }
+  }
+  return op;
+}

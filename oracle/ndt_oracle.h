@@ -1,0 +1,146 @@
+/*
+ * ndt_oracle.h -- CPU restatement of the reference's NDT scan-matching hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under ndt_slam_amd/ (the product) may include,
+ * link or call this.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg use it, and only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the arithmetic of this path lives in PCL
+ * (pcl::NormalDistributionsTransform, pcl::VoxelGridCovariance,
+ * pcl::Registration::getFitnessScore, pcl::transformPointCloud), an un-vendored,
+ * version-unpinned dependency of the reference (CMakeLists.txt:21
+ * `find_package(PCL 1.2 REQUIRED)`), absent from /root/reference and from this image.
+ * The reference ships no tests, fixtures or golden vectors.  This file
+ * restates the published algorithm (Magnusson 2009 eqs 6.8-6.21 / Algorithm 2;
+ * More & Thuente 1994; Sun & Yuan 2006 eqs 2.4.2/2.4.5/2.4.52/2.4.56) with the
+ * PCL <= 1.10 semantics listed in SURVEY.md 8a rows a1-a9, anchored on the
+ * reference's call sites:
+ *     src/PoseEstimator.cpp:4-69          (order of calls, units, 3x3 extraction)
+ *     include/ndt_slam/PoseEstimator.h:63-104 (parameters, z = 0 clouds)
+ *     ndt_mapping.launch:30-36            (parameter values)
+ * Every version-sensitive PCL detail (SURVEY.md 8c list) is a named switch in
+ * ndt_oracle_params.
+ */
+#ifndef NDT_ORACLE_H_
+#define NDT_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Parameters.  Layout is shared (field for field) with include/ndt_mi355x.h's
+ * ndt_params so tests can pass one ctypes struct to both sides. */
+typedef struct ndt_oracle_params {
+  float  resolution;        /* PoseEstimator.h:81 ndt.setResolution (float in PCL)            */
+  double step_size;         /* PoseEstimator.h:79 ndt.setStepSize                             */
+  double trans_eps;         /* PoseEstimator.h:77 ndt.setTransformationEpsilon                */
+  int    max_iter;          /* PoseEstimator.h:83 ndt.setMaximumIterations                    */
+  double outlier_ratio;     /* PCL default 0.55                                               */
+  int    min_pts;           /* VoxelGridCovariance min_points_per_voxel_ = 6                  */
+  double eig_mult;          /* VoxelGridCovariance min_covar_eigvalue_mult_ = 0.01            */
+  /* ---- version-sensitive switches; defaults = PCL <= 1.10 as surveyed ---- */
+  int    cov_unbiased;      /* (1) 0: (Sxx/n - mu mu^T)(n-1)/n   1: /(n-1)                     */
+  int    cov_init_identity; /* (1b) 1: per-voxel Sxx accumulator starts at I (old PCL Leaf())  */
+  int    conv_ge;           /* (2) 0: stop when iter > max_iter  1: iter >= max_iter           */
+  int    radius_inclusive;  /* (4) 0: d^2 < r^2                  1: d^2 <= r^2                 */
+  int    transform_sse;     /* (12) 0: ((m00 x + m01 y) + m03)   1: m00 x + (m01 y + m03)      */
+  int    stale_h_ang;       /* (8) 1: Hessian-only pass after an MT inner loop re-uses the
+                                     2nd-derivative angle terms of the FIRST trial of that
+                                     line search (PCL computeHessian does not refresh them)   */
+  double snap_thresh;       /* (6) small-angle snap, PCL `fabs(p) < 10e-5`                     */
+  int    mt_max_iter;       /* (11) 10                                                         */
+  double mt_mu;             /* (11) 1e-4                                                       */
+  double mt_nu;             /* (11) 0.9                                                        */
+} ndt_oracle_params;
+
+/* Result of one match.  Layout shared with include/ndt_mi355x.h's ndt_result. */
+typedef struct ndt_oracle_result {
+  double pose[3];     /* x, y, yaw[rad] recovered from the float32 matrix by the a9 branch logic
+                         (src/PoseEstimator.cpp:29-36)                                           */
+  float  T00, T10, T03, T13; /* float32 entries of getFinalTransformation()                        */
+  double fitness;     /* getFitnessScore(): mean squared distance to nearest raw map point (m^2) */
+  double trans_prob;  /* getTransformationProbability(): score / N                               */
+  double score;       /* score at the last evaluation                                            */
+  double H[9];        /* d2 score / dp2 (tx,ty,yaw[rad]) at the final cloud, row-major = the
+                         {0,1,5} block of PCL's 6x6 (src/PoseEstimator.cpp:53-61 before the sign) */
+  double p[3];        /* final fp64 parameter vector (tx,ty,yaw)                                 */
+  int    iters;       /* nr_iterations_                                                          */
+  int    evals;       /* derivative passes executed by THIS implementation                       */
+  int    ref_evals;   /* passes the reference executes for the same path (incl. Hessian-only
+                         passes and the a8 getHessian pass)                                      */
+  int    converged;   /* hasConverged()                                                          */
+  int    status;      /* 0 ok; <0 error                                                          */
+  int    pad_;
+  double kbar;        /* mean in-radius cells per point-evaluation                               */
+} ndt_oracle_result;
+
+typedef struct ndt_oracle_map ndt_oracle_map;
+
+void ndt_oracle_default_params(ndt_oracle_params *p);
+
+/* a2: VoxelGridCovariance::filter(true) over a z=0 cloud.  xy points at byte stride. */
+ndt_oracle_map *ndt_oracle_map_build(const float *xy, size_t n, size_t stride_bytes,
+                                     const ndt_oracle_params *prm);
+void ndt_oracle_map_destroy(ndt_oracle_map *m);
+
+/* Introspection used by the parity tests (cell table compared field by field). */
+typedef struct ndt_oracle_map_info {
+  int min_bx, min_by, div_x, div_y;
+  int n_cells;      /* voxels with >= min_pts points (members of the centroid search set) */
+  int n_valid;      /* of those, voxels with an accepted covariance                        */
+  size_t n_points;
+} ndt_oracle_map_info;
+void ndt_oracle_map_info_get(const ndt_oracle_map *m, ndt_oracle_map_info *out);
+/* Export the cell table in ascending dense-index order.  Arrays sized n_cells.
+ * cell_idx = iy*div_x+ix ; cent = float32 centroid xy ; mean = fp64 mean xy ;
+ * icov = xx,xy,yy ; npts = point count (negative => rejected covariance, icov = 0). */
+void ndt_oracle_map_export(const ndt_oracle_map *m, int *cell_idx, float *cent, double *mean,
+                           double *icov, int *npts);
+
+/* a4+a5 at an explicit pose: transform with the float32 matrix built from p (as the line
+ * search does), then score/gradient/Hessian.  g[3], H[9].  Returns score. */
+double ndt_oracle_eval_at(const ndt_oracle_map *m, const float *scan_xy, size_t n,
+                          size_t stride_bytes, const double p[3], double g[3], double H[9],
+                          double *pairs_out);
+
+/* a3-a9: one complete match (align + fitness + final Hessian + a9 extraction).
+ * init = (tx, ty, yaw[rad]) exactly as src/PoseEstimator.cpp:22-24 feeds them
+ * (yaw = DEG2RAD(initPose.th)).  trace (optional, may be NULL): per derivative pass
+ * 8 doubles {a_t, score, g0,g1,g2, p0,p1,p2}; trace_cap passes at most. */
+int ndt_oracle_align(const ndt_oracle_map *m, const float *scan_xy, size_t n, size_t stride_bytes,
+                     const double init[3], ndt_oracle_result *res, double *trace, int trace_cap);
+
+/* Batch of independent matches; offsets[B+1] in points; inits B x 3.
+ * nthreads <= 1: scalar loop; > 1: OpenMP over scans when built with -fopenmp. */
+int ndt_oracle_align_batch(const ndt_oracle_map *m, const float *scans_xy,
+                           const uint64_t *offsets, int B, const double *inits,
+                           ndt_oracle_result *res, int nthreads);
+
+/* a7 alone at an explicit float32 matrix (c, s, tx, ty). */
+double ndt_oracle_fitness(const ndt_oracle_map *m, const float *scan_xy, size_t n,
+                          size_t stride_bytes, float c, float s, float tx, float ty);
+
+/* a1: ApproximateVoxelGrid::filter on a z=0 cloud (src/PoseEstimator.cpp:6-10).
+ * out_xy must hold 2*n floats.  Returns number of output points. */
+size_t ndt_oracle_approx_voxel_filter(const float *xy, size_t n, size_t stride_bytes, float leaf,
+                                      float *out_xy);
+
+/* a9 alone: yaw from float32 matrix entries (src/PoseEstimator.cpp:31-35). */
+double ndt_oracle_yaw_from_T(float T00, float T10);
+
+/* More-Thuente pieces exposed for known-answer tests. */
+double ndt_oracle_mt_trial(double a_l, double f_l, double g_l, double a_u, double f_u, double g_u,
+                           double a_t, double f_t, double g_t);
+int ndt_oracle_mt_update(double *a_l, double *f_l, double *g_l, double *a_u, double *f_u,
+                         double *g_u, double a_t, double f_t, double g_t);
+void ndt_oracle_gauss(const ndt_oracle_params *prm, double *d1, double *d2);
+/* 3x3 symmetric pseudo-inverse solve H x = b (stands in for the 6x6 JacobiSVD solve). */
+void ndt_oracle_solve3(const double H[9], const double b[3], double x[3]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
