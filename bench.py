@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- scan-matches/sec of the NDT hot path on MI355X (BASELINE.json metric).
+
+Workload (config.workload): BASELINE.json configs[2] per GPU -- a batch of 256 scans (10k points
+each) against a shared 1M-point NDT map at 0.5 m voxels; with --gpus N every rank holds its own
+256-scan shard of configs[3]'s batch (weak scaling, no data-path collective; results are gathered
+to rank 0 over RCCL).  configs[1] (one scan) is the same kernel at B = 1 and is reported as
+`single_scan_ms`.
+
+One step = the whole hot path over one batch with inputs resident in HBM: voxel
+normal-distributions build of the map (once per batch; the reference rebuilds it on every
+estimatePose call, src/PoseEstimator.cpp:19) + all 256 full optimisations to convergence +
+fitness scores + final Hessians, then the gather of the 256 result records.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def algorithmic_bytes(res, n_pts):
+    """per point-evaluation 8 B (float2 point) + Kbar x 20 B (mu + Sigma^-1 as
+    float32 equivalents); per match E x N x (8 + 20 Kbar) + N x 16 for the fitness pass."""
+    ev = res["evals"].astype(np.float64)
+    kb = res["kbar"].astype(np.float64)
+    return float(np.sum(ev * n_pts * (8.0 + 20.0 * kb) + n_pts * 16.0))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="scans per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=192, help="scans timed on the host cores")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from ndt_slam_amd import capi, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the NDT core has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    cfg = synth.CONFIGS["C3"]
+    B, n_scan = args.batch, cfg["n_scan"]
+    # synthetic inputs (no reference data exists): same map on every rank, own scan shard
+    map_xy = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(map_xy, cfg["half"], n_scan)
+    scans, off, truths, inits = sf.batch(rank * B, B)
+
+    ctx = capi.Context(local_rank)
+    stream = torch.cuda.current_stream()
+    ctx.set_stream(stream.cuda_stream)      # map build and matches ordered on torch's stream
+    prm = capi.default_params(resolution=cfg["resolution"])     # otherwise ndt_mapping.launch:32-36
+    d_map = torch.from_numpy(map_xy).to(dev)
+    d_scans = torch.from_numpy(scans).to(dev)
+    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    d_init = torch.from_numpy(inits).to(dev)
+    d_res = torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+    gathered = [torch.zeros_like(d_res) for _ in range(world)] if (world > 1 and rank == 0) else None
+    torch.cuda.synchronize()
+    gmap = capi.Map(ctx, params=prm, dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
+
+    ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup))]
+    map_ms = []
+
+    def step(i):
+        # a2: rebuild the voxel grid in place (synchronous on the context stream)
+        gmap.rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
+        map_ms.append(ctx.last_timing()[0])
+        # a3-a9 for the whole batch: one launch on torch's current stream
+        ev_a[2 * i].record(stream)
+        gmap.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, d_init.data_ptr(), d_res.data_ptr(),
+                             stream=stream.cuda_stream)
+        ev_a[2 * i + 1].record(stream)
+        if world > 1:    # gather of poses (the only collective on this path)
+            dist.gather(d_res, gathered, dst=0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, args.warmup + args.steps):
+        step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kern_ms = [ev_a[2 * i].elapsed_time(ev_a[2 * i + 1]) for i in range(args.warmup, args.warmup + args.steps)]
+    res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
+    assert np.all(res["status"] == 0)
+
+    out = None
+    if rank == 0:
+        avg_kern_ms = float(np.mean(kern_ms))
+        alg_bytes = algorithmic_bytes(res, n_scan)
+        achieved = alg_bytes / (avg_kern_ms * 1e-3) / 1e9
+        err = res["pose"] - truths
+        err[:, 2] = (err[:, 2] + math.pi) % (2 * math.pi) - math.pi
+        out = {
+            "metric": "scan-matches/sec (10k-pt scan vs 1M-pt NDT map)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "matches/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: batch of %d scans x %d pts vs shared %d-pt map, 0.5 m "
+                                   "voxels, per GPU (configs[3] sharding at N>1); map rebuilt every step"
+                                   % (B, n_scan, cfg["n_map"]),
+                       "scans_per_gpu": B, "scan_points": n_scan, "map_points": cfg["n_map"],
+                       "resolution": cfg["resolution"], "parallelism": "scan-shards x%d, gather of results" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "ndt_align_kernel", "kernel_ms": avg_kern_ms,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "mean_evals": float(res["evals"].mean()), "max_evals": int(res["evals"].max()),
+                         "mean_kbar": float(res["kbar"].mean())},
+            "map_build_ms": float(np.mean(map_ms[args.warmup:])),
+            "converged": int(res["converged"].sum()),
+            "median_abs_err_m": float(np.median(np.hypot(err[:, 0], err[:, 1]))),
+        }
+
+    # configs[1]: one scan (latency of a single match, same kernel at B = 1)
+    if rank == 0 and world == 1:
+        one = torch.zeros(capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(5):
+            e0.record(stream)
+            gmap.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), 1, d_init.data_ptr(), one.data_ptr(),
+                                 stream=stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        out["single_scan_ms"] = float(np.median(ts))
+
+    # CPU baseline: the oracle (a port -- PCL itself is absent) on this box's host cores,
+    # rank 0 at N = 1 only, on a bounded sample of the same batch.
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ndt_oracle as O
+        ns = min(args.cpu_sample, B)
+        t = time.perf_counter()
+        om = O.Map(map_xy, O.default_params(resolution=cfg["resolution"]))
+        t_build = time.perf_counter() - t
+        sub_off = off[:ns + 1]
+        t = time.perf_counter()
+        ref = om.align_batch(scans[:int(sub_off[-1])], sub_off, inits[:ns], nthreads=1)
+        t_align = time.perf_counter() - t
+        ncpu = os.cpu_count() or 1
+        t = time.perf_counter()
+        om.align_batch(scans[:int(sub_off[-1])], sub_off, inits[:ns], nthreads=ncpu)
+        t_all = time.perf_counter() - t
+        d = res["pose"][:ns] - ref["pose"]
+        d[:, 2] = (d[:, 2] + math.pi) % (2 * math.pi) - math.pi
+        out["cpu_baseline"] = {
+            "value": ns / t_align, "unit": "matches/s", "cores": 1, "kind": "port",
+            "sample": "first %d of the %d scans, 1 thread, map built once (amortised); oracle/ndt_oracle.c" % (ns, B),
+            "map_build_s": t_build,
+            "reference_faithful_matches_per_s": 1.0 / (t_build + t_align / ns),
+            "all_cores": {"value": ns / t_all, "cores": ncpu},
+        }
+        out["parity"] = {"max_dpos_m": float(np.abs(d[:, :2]).max()), "max_dyaw_rad": float(np.abs(d[:, 2]).max()),
+                         "same_iters": bool(np.all(res["iters"][:ns] == ref["iters"])), "sample": ns}
+        out["gpu_over_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,164 @@
+/*
+ * ndt_mi355x.h -- C ABI of the MI355X-native NDT scan-matching core (libndt_mi355x.so).
+ *
+ * Drop-in boundary.  The reference has no FFI: its hot path sits behind the
+ * concrete C++ class PoseEstimator (include/ndt_slam/PoseEstimator.h:36-133), injected by
+ * pointer (src/SlamLauncher.cpp:12 -> include/ndt_slam/FrontEnd.h:74-76 ->
+ * include/ndt_slam/ScanMatcher.h:58-60) and called only from ScanMatcher::matchScan
+ * (src/ScanMatcher.cpp:40,45).  A replacement PoseEstimator.{h,cpp} binds exactly the entry
+ * points below; INTEGRATION.md shows that binding.  Each entry point names the reference
+ * interface (file:line) it replaces.  Plain pointers and sizes only; never throws; every
+ * function returns 0 on success or a negative ndt_status, with text in ndt_last_error().
+ *
+ * Threading: a context is bound to one device and one host thread; all GPU work runs on the
+ * context's stream (or the stream passed to the *_dev calls).  Host-pointer calls are
+ * synchronous on return; *_dev calls are asynchronous on their stream.
+ */
+#ifndef NDT_MI355X_H_
+#define NDT_MI355X_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum ndt_status {
+  NDT_OK = 0,
+  NDT_E_ARG = -1,        /* null / empty / inconsistent arguments                     */
+  NDT_E_HIP = -2,        /* a HIP runtime call failed (text in ndt_last_error)        */
+  NDT_E_NO_DEVICE = -3,  /* no gfx950 device: the library never falls back to the CPU */
+  NDT_E_GRID = -4,       /* map extent / resolution needs more than 2^28 voxels       */
+  NDT_E_NOMEM = -5
+};
+
+/* Parameters of the path.  The first four are the ROS parameters the reference's constructor
+ * reads and hands to PCL (include/ndt_slam/PoseEstimator.h:63-84; values in
+ * ndt_mapping.launch:32-36); the rest are PCL defaults and the version-sensitive switches of
+ * SURVEY.md 8c (defaults = PCL <= 1.10 as surveyed). */
+typedef struct ndt_params {
+  float  resolution;        /* PoseEstimator.h:81  ndt.setResolution             */
+  double step_size;         /* PoseEstimator.h:79  ndt.setStepSize               */
+  double trans_eps;         /* PoseEstimator.h:77  ndt.setTransformationEpsilon  */
+  int    max_iter;          /* PoseEstimator.h:83  ndt.setMaximumIterations      */
+  double outlier_ratio;     /* 0.55 */
+  int    min_pts;           /* 6    */
+  double eig_mult;          /* 0.01 */
+  int    cov_unbiased;      /* 0: (Sxx/n - mu mu^T)(n-1)/n ; 1: /(n-1)           */
+  int    cov_init_identity; /* 1: per-voxel Sxx accumulator starts at I          */
+  int    conv_ge;           /* 0: stop when iter > max_iter ; 1: >=              */
+  int    radius_inclusive;  /* 0: d^2 < r^2 ; 1: <=                              */
+  int    transform_sse;     /* 0: (m00 x + m01 y) + m03 ; 1: m00 x + (m01 y + m03) */
+  int    stale_h_ang;       /* 1: Hessian after an inner line search uses the 2nd-derivative
+                                  angle terms of that line search's first trial  */
+  double snap_thresh;       /* 10e-5 */
+  int    mt_max_iter;       /* 10    */
+  double mt_mu;             /* 1e-4  */
+  double mt_nu;             /* 0.9   */
+} ndt_params;
+
+/* Result of one scan-to-map match = everything src/PoseEstimator.cpp:28-64 reads back from
+ * PCL after ndt.align(). */
+typedef struct ndt_result {
+  double pose[3];     /* x, y, yaw[rad] by the asin/acos branch logic of src/PoseEstimator.cpp:31-35
+                         applied to the float32 matrix entries below                               */
+  float  T00, T10, T03, T13; /* getFinalTransformation() entries (src/PoseEstimator.cpp:29)        */
+  double fitness;     /* getFitnessScore() (src/PoseEstimator.cpp:43), m^2; the 1e7 sentinel of
+                         :44-46 is applied by the shim, not here                                   */
+  double trans_prob;  /* getTransformationProbability() (src/PoseEstimator.cpp:48)                 */
+  double score;
+  double H[9];        /* rows/cols {0,1,5} of getHessian()'s 6x6 (src/PoseEstimator.cpp:53-61),
+                         row-major, before the sign flip of :61                                    */
+  double p[3];        /* final fp64 parameter vector (tx, ty, yaw)                                 */
+  int    iters;       /* outer Newton iterations                                                   */
+  int    evals;       /* derivative passes this library executed                                   */
+  int    ref_evals;   /* passes the reference executes on the same path (adds its Hessian-only
+                         passes and the getHessian pass, which are fused here)                     */
+  int    converged;   /* hasConverged() (src/PoseEstimator.cpp:44)                                 */
+  int    status;      /* ndt_status of this match                                                  */
+  int    pad_;
+  double kbar;        /* mean in-radius cells per point-evaluation (roofline accounting)           */
+} ndt_result;
+
+typedef struct ndt_map_info {
+  int min_bx, min_by, div_x, div_y;
+  int n_cells;   /* voxels with >= min_pts points */
+  int n_valid;   /* of those, accepted covariances */
+  size_t n_points;
+} ndt_map_info;
+
+typedef struct ndt_ctx ndt_ctx;
+typedef struct ndt_map ndt_map;
+
+/* PCL-side defaults + include/ndt_slam/PoseEstimator.h:63-64 constructor defaults. */
+int ndt_default_params(ndt_params *p);
+
+/* One context per process and device (one process per GPU).  device = HIP ordinal. */
+int ndt_ctx_create(int device, ndt_ctx **out);
+int ndt_ctx_destroy(ndt_ctx *ctx);
+const char *ndt_last_error(const ndt_ctx *ctx);   /* ctx may be NULL: last global error */
+void *ndt_ctx_stream(ndt_ctx *ctx);               /* hipStream_t the context works on   */
+/* Make the context work on a caller-owned hipStream_t (e.g. the stream a host framework already
+ * orders its copies on); NULL restores the context's own stream. */
+int ndt_ctx_set_stream(ndt_ctx *ctx, void *stream);
+
+/* Replaces ndt.setInputTarget(target_cloud) (src/PoseEstimator.cpp:19): voxel-grid
+ * normal-distributions build plus the raw-point buckets the fitness
+ * score searches (replaces the kd-tree Registration::initCompute builds, row a7).
+ * xy: points at `stride_bytes` (8 = packed float2, 16 = pcl::PointXYZ).  If *map is non-NULL
+ * it is rebuilt in place (the reference's target cloud is refilled every scan,
+ * src/PointCloudMap.cpp:119-131).  Host-pointer form copies to the device first. */
+int ndt_map_build(ndt_ctx *ctx, const float *xy_host, size_t n, size_t stride_bytes,
+                  const ndt_params *prm, ndt_map **map);
+int ndt_map_build_dev(ndt_ctx *ctx, const float *xy_dev, size_t n, size_t stride_bytes,
+                      const ndt_params *prm, ndt_map **map);
+int ndt_map_destroy(ndt_map *map);
+int ndt_map_info_get(const ndt_map *map, ndt_map_info *out);
+/* Cell table in ascending voxel-index order, arrays sized n_cells (parity tests). */
+int ndt_map_export(const ndt_map *map, int *cell_idx, float *cent_xy, double *mean_xy,
+                   double *icov_xx_xy_yy, int *npts);
+
+/* Replaces ndt.setInputSource + ndt.align + getFinalTransformation + getFitnessScore +
+ * hasConverged + getTransformationProbability + getHessian for ONE scan
+ * (src/PoseEstimator.cpp:17-56).  scan = the post-filter source cloud (row a1 stays with the
+ * caller); init = (tx, ty, yaw[rad]) as src/PoseEstimator.cpp:22-24 builds the guess. */
+int ndt_align(ndt_ctx *ctx, const ndt_map *map, const float *scan_xy_host, size_t n,
+              size_t stride_bytes, const double init_xyyaw[3], ndt_result *out);
+
+/* Batch of B independent matches against one map (BASELINE.json configs 3-5).  Scans are
+ * packed float2, concatenated; offsets[B+1] in points.  shared_scan != 0: every match uses
+ * scan 0 (offsets[0..1]) with its own init pose (multi-hypothesis relocalisation). */
+int ndt_align_batch(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_host,
+                    const uint64_t *offsets_host, int B, int shared_scan,
+                    const double *inits_host /* B x 3 */, ndt_result *out_host /* B */);
+/* Same with every buffer resident in device memory; asynchronous on `stream`
+ * (NULL = the context's stream).  out_dev receives B ndt_result records. */
+int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_dev,
+                        const uint64_t *offsets_dev, int B, int shared_scan,
+                        const double *inits_dev, ndt_result *out_dev, void *stream);
+/* As ndt_align_batch, additionally recording per derivative pass of every match
+ * 8 doubles {a_t, score, g0, g1, g2, p0, p1, p2} (parity tests: same step sequence as the
+ * oracle).  trace_host: B x trace_cap x 8 doubles; trace_rows_host: B ints. */
+int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_host,
+                          const uint64_t *offsets_host, int B, int shared_scan,
+                          const double *inits_host, ndt_result *out_host, double *trace_host,
+                          int trace_cap, int *trace_rows_host);
+
+/* One derivative pass at an explicit pose (rows a4+a5; parity tests and profiling):
+ * score, gradient[3], Hessian[9] of d(score)/dp at p = (tx, ty, yaw). */
+int ndt_eval_at(ndt_ctx *ctx, const ndt_map *map, const float *scan_xy_host, size_t n,
+                size_t stride_bytes, const double p[3], double *score, double g[3], double H[9],
+                double *pairs);
+/* Fitness score alone at an explicit float32 transform (row a7). */
+int ndt_fitness_at(ndt_ctx *ctx, const ndt_map *map, const float *scan_xy_host, size_t n,
+                   size_t stride_bytes, float c, float s, float tx, float ty, double *fitness);
+
+/* Timing hooks used by bench.py (HIP events on the context's stream; milliseconds of the most
+ * recent call of each kind, measured around the kernel launches only). */
+int ndt_last_timing(const ndt_ctx *ctx, float *map_build_ms, float *align_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,39 @@
+"""Builds libndt_mi355x.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SRC = os.path.join(HERE, "csrc", "ndt_mi355x.hip")
+OUT = os.path.join(HERE, "libndt_mi355x.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+         "-ffp-contract=off",            # explicit fma only (see the header of the .hip file)
+         "-fno-fast-math", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+         "-I" + os.path.join(ROOT, "include")]
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [SRC, os.path.join(ROOT, "include", "ndt_mi355x.h"), __file__]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False, extra=()):
+    if not force and not needs_build():
+        return OUT
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True,
+          extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else [])
+    print(OUT)

@@ -1,0 +1,235 @@
+"""ctypes binding of libndt_mi355x.so (include/ndt_mi355x.h).
+
+This is the only way Python reaches the kernels: every call goes through the C ABI a C++
+maintainer of the reference would bind.  There is no CPU fallback: a missing
+library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libndt_mi355x.so")
+_LIB = None
+
+
+class NdtError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """ndt_params (include/ndt_mi355x.h)."""
+    _fields_ = [
+        ("resolution", C.c_float), ("step_size", C.c_double), ("trans_eps", C.c_double),
+        ("max_iter", C.c_int), ("outlier_ratio", C.c_double), ("min_pts", C.c_int),
+        ("eig_mult", C.c_double), ("cov_unbiased", C.c_int), ("cov_init_identity", C.c_int),
+        ("conv_ge", C.c_int), ("radius_inclusive", C.c_int), ("transform_sse", C.c_int),
+        ("stale_h_ang", C.c_int), ("snap_thresh", C.c_double), ("mt_max_iter", C.c_int),
+        ("mt_mu", C.c_double), ("mt_nu", C.c_double),
+    ]
+
+
+class MapInfo(C.Structure):
+    _fields_ = [("min_bx", C.c_int), ("min_by", C.c_int), ("div_x", C.c_int), ("div_y", C.c_int),
+                ("n_cells", C.c_int), ("n_valid", C.c_int), ("n_points", C.c_size_t)]
+
+
+# ndt_result as a numpy record (same layout as the C struct)
+RESULT_DTYPE = np.dtype([
+    ("pose", "f8", 3), ("T00", "f4"), ("T10", "f4"), ("T03", "f4"), ("T13", "f4"),
+    ("fitness", "f8"), ("trans_prob", "f8"), ("score", "f8"), ("H", "f8", 9), ("p", "f8", 3),
+    ("iters", "i4"), ("evals", "i4"), ("ref_evals", "i4"), ("converged", "i4"), ("status", "i4"),
+    ("pad_", "i4"), ("kbar", "f8")], align=True)
+RESULT_BYTES = RESULT_DTYPE.itemsize
+
+EXPORTS = [
+    "ndt_default_params", "ndt_ctx_create", "ndt_ctx_destroy", "ndt_last_error", "ndt_ctx_stream",
+    "ndt_ctx_set_stream",
+    "ndt_map_build", "ndt_map_build_dev", "ndt_map_destroy", "ndt_map_info_get", "ndt_map_export",
+    "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_trace", "ndt_eval_at",
+    "ndt_fitness_at", "ndt_last_timing",
+]
+
+
+def lib():
+    """Load the shared library; fail loudly when it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB_PATH):
+        raise NdtError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    L.ndt_default_params.argtypes = [C.POINTER(Params)]
+    L.ndt_ctx_create.argtypes = [i, C.POINTER(vp)]
+    L.ndt_ctx_destroy.argtypes = [vp]
+    L.ndt_last_error.restype = C.c_char_p
+    L.ndt_last_error.argtypes = [vp]
+    L.ndt_ctx_stream.restype = vp
+    L.ndt_ctx_stream.argtypes = [vp]
+    L.ndt_ctx_set_stream.argtypes = [vp, vp]
+    L.ndt_map_build.argtypes = [vp, vp, sz, sz, C.POINTER(Params), C.POINTER(vp)]
+    L.ndt_map_build_dev.argtypes = [vp, vp, sz, sz, C.POINTER(Params), C.POINTER(vp)]
+    L.ndt_map_destroy.argtypes = [vp]
+    L.ndt_map_info_get.argtypes = [vp, C.POINTER(MapInfo)]
+    L.ndt_map_export.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.ndt_align.argtypes = [vp, vp, vp, sz, sz, vp, vp]
+    L.ndt_align_batch.argtypes = [vp, vp, vp, vp, i, i, vp, vp]
+    L.ndt_align_batch_dev.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp]
+    L.ndt_align_batch_trace.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, i, vp]
+    L.ndt_eval_at.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp, vp, vp]
+    L.ndt_fitness_at.argtypes = [vp, vp, vp, sz, sz, C.c_float, C.c_float, C.c_float, C.c_float, vp]
+    L.ndt_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    for name in EXPORTS:
+        if name not in ("ndt_last_error", "ndt_ctx_stream"):
+            getattr(L, name).restype = i
+    _LIB = L
+    return L
+
+
+def default_params(**kw):
+    p = Params()
+    lib().ndt_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _f32c(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if a.ndim != 2 or a.shape[1] != 2:
+        raise ValueError("expected an [n, 2] float32 array")
+    return a
+
+
+class Context:
+    """ndt_ctx: one per process and device."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        rc = lib().ndt_ctx_create(device, C.byref(self.h))
+        if rc:
+            raise NdtError("ndt_ctx_create(%d) -> %d: %s" % (device, rc, lib().ndt_last_error(None).decode()))
+        self.device = device
+
+    def check(self, rc, what):
+        if rc:
+            raise NdtError("%s -> %d: %s" % (what, rc, lib().ndt_last_error(self.h).decode()))
+
+    @property
+    def stream(self):
+        return lib().ndt_ctx_stream(self.h)
+
+    def set_stream(self, stream):
+        """Order all work of this context on a caller-owned hipStream_t (int handle or None)."""
+        self.check(lib().ndt_ctx_set_stream(self.h, stream), "ndt_ctx_set_stream")
+
+    def last_timing(self):
+        a, b = C.c_float(), C.c_float()
+        lib().ndt_last_timing(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def close(self):
+        if self.h:
+            lib().ndt_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Map:
+    """ndt_map: the NDT voxel grid of one target cloud (replaces ndt.setInputTarget)."""
+
+    def __init__(self, ctx, xy=None, params=None, dev_ptr=None, n=None, stride=8):
+        self.ctx = ctx
+        self.params = params if params is not None else default_params()
+        self.h = C.c_void_p()
+        self.rebuild(xy=xy, dev_ptr=dev_ptr, n=n, stride=stride)
+
+    def rebuild(self, xy=None, dev_ptr=None, n=None, stride=8):
+        if dev_ptr is not None:
+            rc = lib().ndt_map_build_dev(self.ctx.h, dev_ptr, n, stride, C.byref(self.params), C.byref(self.h))
+        else:
+            xy = _f32c(xy)
+            rc = lib().ndt_map_build(self.ctx.h, xy.ctypes.data, len(xy), 8, C.byref(self.params), C.byref(self.h))
+        self.ctx.check(rc, "ndt_map_build")
+
+    def info(self):
+        i = MapInfo()
+        self.ctx.check(lib().ndt_map_info_get(self.h, C.byref(i)), "ndt_map_info_get")
+        return i
+
+    def export(self):
+        n = self.info().n_cells
+        idx = np.zeros(n, np.int32); cent = np.zeros((n, 2), np.float32)
+        mean = np.zeros((n, 2), np.float64); icov = np.zeros((n, 3), np.float64)
+        npts = np.zeros(n, np.int32)
+        self.ctx.check(lib().ndt_map_export(self.h, idx.ctypes.data, cent.ctypes.data, mean.ctypes.data,
+                                            icov.ctypes.data, npts.ctypes.data), "ndt_map_export")
+        return dict(idx=idx, cent=cent, mean=mean, icov=icov, npts=npts)
+
+    def align(self, scan, init):
+        scan = _f32c(scan)
+        init = np.ascontiguousarray(init, dtype=np.float64)
+        res = np.zeros(1, dtype=RESULT_DTYPE)
+        self.ctx.check(lib().ndt_align(self.ctx.h, self.h, scan.ctypes.data, len(scan), 8, init.ctypes.data,
+                                       res.ctypes.data), "ndt_align")
+        return res[0]
+
+    def align_batch(self, scans, offsets, inits, shared_scan=False, trace_cap=0):
+        scans = _f32c(scans)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        inits = np.ascontiguousarray(inits, dtype=np.float64).reshape(-1, 3)
+        B = len(inits)
+        res = np.zeros(B, dtype=RESULT_DTYPE)
+        if trace_cap:
+            trace = np.zeros((B, trace_cap, 8)); rows = np.zeros(B, np.int32)
+            self.ctx.check(lib().ndt_align_batch_trace(
+                self.ctx.h, self.h, scans.ctypes.data, offsets.ctypes.data, B, int(shared_scan),
+                inits.ctypes.data, res.ctypes.data, trace.ctypes.data, trace_cap, rows.ctypes.data),
+                "ndt_align_batch_trace")
+            return res, [trace[b, :min(rows[b], trace_cap)] for b in range(B)]
+        self.ctx.check(lib().ndt_align_batch(self.ctx.h, self.h, scans.ctypes.data, offsets.ctypes.data, B,
+                                             int(shared_scan), inits.ctypes.data, res.ctypes.data),
+                       "ndt_align_batch")
+        return res
+
+    def align_batch_dev(self, scans_ptr, offsets_ptr, B, inits_ptr, out_ptr, shared_scan=False, stream=None):
+        """All pointers are device addresses (e.g. torch.Tensor.data_ptr()); asynchronous."""
+        self.ctx.check(lib().ndt_align_batch_dev(self.ctx.h, self.h, scans_ptr, offsets_ptr, B, int(shared_scan),
+                                                 inits_ptr, out_ptr, stream), "ndt_align_batch_dev")
+
+    def eval_at(self, scan, p):
+        scan = _f32c(scan)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        s = C.c_double(); pr = C.c_double(); g = np.zeros(3); H = np.zeros(9)
+        self.ctx.check(lib().ndt_eval_at(self.ctx.h, self.h, scan.ctypes.data, len(scan), 8, p.ctypes.data,
+                                         C.addressof(s), g.ctypes.data, H.ctypes.data, C.addressof(pr)),
+                       "ndt_eval_at")
+        return s.value, g, H.reshape(3, 3), pr.value
+
+    def fitness_at(self, scan, c, s, tx, ty):
+        scan = _f32c(scan)
+        f = C.c_double()
+        self.ctx.check(lib().ndt_fitness_at(self.ctx.h, self.h, scan.ctypes.data, len(scan), 8, c, s, tx, ty,
+                                            C.addressof(f)), "ndt_fitness_at")
+        return f.value
+
+    def close(self):
+        if self.h:
+            lib().ndt_map_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

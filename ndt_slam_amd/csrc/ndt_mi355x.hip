@@ -1,0 +1,1351 @@
+// ndt_mi355x.hip -- MI355X (gfx950 / CDNA4) NDT scan-matching core + its C ABI.
+//
+// Replaces what the reference delegates to PCL behind PoseEstimator::estimatePose
+// (/root/reference/src/PoseEstimator.cpp:17-56): voxel normal-distributions build (SURVEY.md
+// 8a row a2), SE(2) transform + radius lookup + score/gradient/Hessian accumulation (a4, a5),
+// Newton + More-Thuente pose update (a3, a6), fitness score (a7), final Hessian (a8) and the
+// pose extraction (a9).  Written for 64-wide wavefronts; no MFMA (there is no dense
+// contraction on this path); fp64 accumulation with fixed-order reductions so a run is
+// deterministic and takes the same line-search branches as the CPU oracle.
+//
+// Floating-point contraction is OFF for the whole file (voxel statistics, float32 transform and
+// the optimiser must round like the scalar reference code); the hot accumulation loop asks for
+// fused multiply-adds explicitly with __builtin_fma.
+//
+// This file never includes or calls anything under oracle/.  Without a HIP device every entry
+// point fails with NDT_E_NO_DEVICE: there is no CPU fallback.
+
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "ndt_mi355x.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+thread_local std::string g_last_error;
+
+// ------------------------------------------------------------------------------------------
+// device-side views
+// ------------------------------------------------------------------------------------------
+
+// Dense voxel grid padded by 2 cells on every side so that the 3x3 probe of any point whose
+// voxel lies within one cell of the map's bounding box needs no bounds checks.
+struct MapView {
+  float inv_leaf, leaf, r2;
+  int radius_inclusive, transform_sse;
+  int min_bx, min_by, div_x, div_y;  // unpadded voxel grid (VoxelGridCovariance min_b_/div_b_)
+  int gw, gh;                        // padded: div + 4
+  const float2 *cent;                // gw*gh float32 centroids; +inf where the voxel is not in
+                                     // the centroid search set (fewer than min_pts points)
+  const double *rec;                 // gw*gh records of 8 doubles (64 B):
+                                     // mean_x, mean_y, icov_xx, icov_xy, icov_yy, 3 pad
+  const int *pt_start;               // div_x*div_y + 1 bucket offsets of the raw points
+  const float2 *pts;                 // raw points bucketed by voxel, input order kept (a7)
+  double d1, d2;                     // Gaussian constants (a3)
+};
+
+struct OptParams {
+  double step_size, trans_eps, snap_thresh, mt_mu, mt_nu;
+  int max_iter, conv_ge, stale_h_ang, mt_max_iter;
+};
+
+struct Tf32 { float c, s, tx, ty; };
+
+// eleven partial sums of one derivative pass
+struct Acc {
+  double e, g0, g1, g2, hxx, hxy, hxt, hyy, hyt, htt, pairs;
+};
+constexpr int kAcc = 11;
+
+enum Phase : int { PH_INIT = 0, PH_LS_FIRST = 1, PH_LS_INNER = 2, PH_DONE = 3 };
+
+// Resumable optimiser state of one match.  One lane advances it after every derivative pass;
+// kept free of any per-workgroup assumption so a pass can be produced by any set of waves.
+struct AlignState {
+  int phase, iters, evals, ref_evals, converged, step_iterations, open_interval, interval_converged;
+  Tf32 T;                       // final_transformation_ (float32)
+  double cj, sj, ch, sh;        // angle terms of J_E and of the (yaw,yaw) block of H_E
+  double p[3], dir[3], xt[3];
+  double score, g[3], H[6];     // xx xy xt yy yt tt
+  double phi0, dphi0, a_l, f_l, g_l, a_u, f_u, g_u, a_t;
+  double pairs;
+  double n_points;
+};
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float2 load_pt(const float *xy, size_t stride, size_t i) {
+  return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(xy) + i * stride);
+}
+
+// float32 matrix of the fp64 parameter vector (a4): Translation3f(float(p0), float(p1), 0) *
+// AngleAxisf(float(p2), Z); std::cos/std::sin(float) modelled as correctly rounded.
+__device__ __forceinline__ Tf32 tf_from_p(const double p[3]) {
+  Tf32 t;
+  float yaw = (float)p[2];
+  t.c = (float)cos((double)yaw);
+  t.s = (float)sin((double)yaw);
+  t.tx = (float)p[0];
+  t.ty = (float)p[1];
+  return t;
+}
+
+// pcl::transformPointCloud on a z = 0 point, float32, no contraction.
+__device__ __forceinline__ void tf_apply(const Tf32 &t, int sse, float x, float y, float &ox,
+                                         float &oy) {
+  float ms = -t.s;
+  float a = t.c * x, b = ms * y, c = t.s * x, d = t.c * y;
+  if (!sse) {
+    float r = a + b; ox = r + t.tx;
+    float q = c + d; oy = q + t.ty;
+  } else {
+    float r = b + t.tx; ox = a + r;
+    float q = d + t.ty; oy = c + q;
+  }
+}
+
+__device__ __forceinline__ bool finite2(float x, float y) {
+  return (fabsf(x) <= FLT_MAX) && (fabsf(y) <= FLT_MAX);
+}
+
+__device__ __forceinline__ void angle_cs(double snap, double yaw, double &c, double &s) {
+  if (fabs(yaw) < snap) { c = 1.0; s = 0.0; }
+  else { c = cos(yaw); s = sin(yaw); }
+}
+
+// ------------------------------------------------------------------------------------------
+// a4 + a5: one source point -> its in-radius voxels -> score / gradient / Hessian terms
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void eval_point(const MapView &M, const Tf32 &T, float x, float y,
+                                           double cj, double sj, double ch, double sh, Acc &A) {
+  float xt, yt;
+  tf_apply(T, M.transform_sse, x, y, xt, yt);
+  if (!finite2(xt, yt)) return;
+  int ix = (int)floorf(xt * M.inv_leaf) - M.min_bx;
+  int iy = (int)floorf(yt * M.inv_leaf) - M.min_by;
+  if (ix < -1 || ix > M.div_x || iy < -1 || iy > M.div_y) return;
+  const int px = ix + 2, py = iy + 2;
+  const float2 *crow = M.cent + (size_t)(py - 1) * M.gw + (px - 1);
+  // radius search over voxel centroids (r = resolution): subset of the 3x3 neighbourhood.
+  unsigned mask = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      float2 cc = crow[r * M.gw + q];
+      float ex = xt - cc.x, ey = yt - cc.y;
+      float dd = ex * ex + ey * ey;                      // flann::L2_Simple<float>
+      bool in = M.radius_inclusive ? (dd <= M.r2) : (dd < M.r2);
+      mask |= (in ? 1u : 0u) << (r * 3 + q);
+    }
+  }
+  if (!mask) return;
+  // yaw column of J_E and the (yaw,yaw) block of H_E (untransformed coordinates)
+  const double X = (double)x, Y = (double)y;
+  const double jx = X * (-sj) + Y * (-cj);
+  const double jy = X * cj + Y * (-sj);
+  const double hx = X * (-ch) + Y * sh;
+  const double hy = X * (-sh) + Y * (-ch);
+  const double XT = (double)xt, YT = (double)yt;
+  const double nd2 = -M.d2;
+  while (mask) {
+    int k = __builtin_ctz(mask);
+    mask &= mask - 1;
+    int r = k / 3, q = k - 3 * r;
+    const double *rec = M.rec + ((size_t)(py - 1 + r) * M.gw + (px - 1 + q)) * 8;
+    const double2 mu = *reinterpret_cast<const double2 *>(rec);
+    const double2 ia = *reinterpret_cast<const double2 *>(rec + 2);
+    const double i11 = rec[4];
+    const double i00 = ia.x, i01 = ia.y;
+    const double q0 = XT - mu.x, q1 = YT - mu.y;
+    const double u0 = __builtin_fma(i01, q1, i00 * q0);      // Sigma^-1 q
+    const double u1 = __builtin_fma(i11, q1, i01 * q0);
+    const double m = __builtin_fma(q1, u1, q0 * u0);
+    double e = exp(nd2 * m * 0.5);
+    const double e2 = M.d2 * e;
+    A.pairs += 1.0;
+    if (e2 > 1.0 || e2 < 0.0 || e2 != e2) e = 0.0;           // updateDerivatives error check
+    const double at = __builtin_fma(u1, jy, u0 * jx);        // q^T Sigma^-1 dT/dyaw
+    const double cx = __builtin_fma(i01, jy, i00 * jx);      // Sigma^-1 dT/dyaw
+    const double cy = __builtin_fma(i11, jy, i01 * jx);
+    const double v0 = nd2 * u0, v1 = nd2 * u1, vt = nd2 * at;
+    A.e += e;
+    A.g0 = __builtin_fma(e, u0, A.g0);
+    A.g1 = __builtin_fma(e, u1, A.g1);
+    A.g2 = __builtin_fma(e, at, A.g2);
+    A.hxx = __builtin_fma(e, __builtin_fma(v0, u0, i00), A.hxx);
+    A.hxy = __builtin_fma(e, __builtin_fma(v0, u1, i01), A.hxy);
+    A.hxt = __builtin_fma(e, __builtin_fma(v0, at, cx), A.hxt);
+    A.hyy = __builtin_fma(e, __builtin_fma(v1, u1, i11), A.hyy);
+    A.hyt = __builtin_fma(e, __builtin_fma(v1, at, cy), A.hyt);
+    double tt = __builtin_fma(jx, cx, jy * cy);              // J^T Sigma^-1 J
+    tt = __builtin_fma(u0, hx, tt);                          // + q^T Sigma^-1 d2T/dyaw2
+    tt = __builtin_fma(u1, hy, tt);
+    tt = __builtin_fma(vt, at, tt);
+    A.htt = __builtin_fma(e, tt, A.htt);
+  }
+}
+
+// Fixed-order sum over the workgroup.  Result valid in thread 0 only (and in sred[0..kAcc)).
+template <int NV>
+__device__ __forceinline__ void block_reduce(double (&v)[NV], double *sred /* [nwaves][NV] + [NV] */) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double x = v[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+    v[i] = x;
+  }
+  __syncthreads();   // sred may still be read by the previous round
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sred[wave * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < NV) {
+    double s = 0.0;
+    for (int w = 0; w < nw; ++w) s += sred[w * NV + threadIdx.x];
+    sred[nw * NV + threadIdx.x] = s;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = sred[nw * NV + i];
+}
+
+// ------------------------------------------------------------------------------------------
+// a6: Newton step + More-Thuente line search as a resumable state machine
+// ------------------------------------------------------------------------------------------
+
+// Symmetric 3x3 pseudo-inverse solve (cyclic Jacobi); stands in for JacobiSVD<6x6>::solve on the
+// block-diagonal 6x6 (SURVEY.md 8a note).
+__device__ __noinline__ void solve3(const double Hs[6], const double b[3], double x[3]) {
+  double A[3][3] = {{Hs[0], Hs[1], Hs[2]}, {Hs[1], Hs[3], Hs[4]}, {Hs[2], Hs[4], Hs[5]}};
+  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      if (A[i][j] != A[i][j]) { x[0] = x[1] = x[2] = NAN; return; }
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
+    if (off == 0.0) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        double apq = A[p][q];
+        if (apq == 0.0) continue;
+        double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        double app = A[p][p], aqq = A[q][q];
+        A[p][p] = app - t * apq; A[q][q] = aqq + t * apq; A[p][q] = A[q][p] = 0.0;
+        int r = 3 - p - q;
+        double arp = A[r][p], arq = A[r][q];
+        A[r][p] = A[p][r] = c * arp - s * arq;
+        A[r][q] = A[q][r] = s * arp + c * arq;
+        for (int k = 0; k < 3; ++k) {
+          double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  double lmax = fmax(fabs(A[0][0]), fmax(fabs(A[1][1]), fabs(A[2][2])));
+  double thr = lmax * (6.0 * DBL_EPSILON);
+  x[0] = x[1] = x[2] = 0.0;
+  for (int k = 0; k < 3; ++k) {
+    double l = A[k][k];
+    if (!(fabs(l) > thr) || fabs(l) < DBL_MIN) continue;
+    double proj = (V[0][k] * b[0] + V[1][k] * b[1] + V[2][k] * b[2]) / l;
+    x[0] += V[0][k] * proj; x[1] += V[1][k] * proj; x[2] += V[2][k] * proj;
+  }
+}
+
+// More-Thuente trial value, cases 1-4 (Sun & Yuan 2.4.2 / 2.4.5 / 2.4.52 / 2.4.56).
+__device__ __noinline__ double mt_trial(double a_l, double f_l, double g_l, double a_u, double f_u,
+                                        double g_u, double a_t, double f_t, double g_t) {
+  if (f_t > f_l) {
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_q = a_l - 0.5 * (a_l - a_t) * g_l / (g_l - (f_l - f_t) / (a_l - a_t));
+    if (fabs(a_c - a_l) < fabs(a_q - a_l)) return a_c;
+    return 0.5 * (a_q + a_c);
+  } else if (g_t * g_l < 0) {
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    if (fabs(a_c - a_t) >= fabs(a_s - a_t)) return a_c;
+    return a_s;
+  } else if (fabs(g_t) <= fabs(g_l)) {
+    double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
+    double w = sqrt(z * z - g_t * g_l);
+    double a_c = a_l + (a_t - a_l) * (w - g_l - z) / (g_t - g_l + 2 * w);
+    double a_s = a_l - (a_l - a_t) / (g_l - g_t) * g_l;
+    double a_n = (fabs(a_c - a_t) < fabs(a_s - a_t)) ? a_c : a_s;
+    double lim = a_t + 0.66 * (a_u - a_t);
+    if (a_t > a_l) return (a_n < lim) ? a_n : lim;
+    return (lim < a_n) ? a_n : lim;
+  } else {
+    double z = 3 * (f_t - f_u) / (a_t - a_u) - g_t - g_u;
+    double w = sqrt(z * z - g_t * g_u);
+    return a_u + (a_t - a_u) * (w - g_u - z) / (g_t - g_u + 2 * w);
+  }
+}
+
+__device__ __forceinline__ int mt_update(AlignState &S, double a_t, double f_t, double g_t) {
+  if (f_t > S.f_l) { S.a_u = a_t; S.f_u = f_t; S.g_u = g_t; return 0; }
+  if (g_t * (S.a_l - a_t) > 0) { S.a_l = a_t; S.f_l = f_t; S.g_l = g_t; return 0; }
+  if (g_t * (S.a_l - a_t) < 0) {
+    S.a_u = S.a_l; S.f_u = S.f_l; S.g_u = S.g_l;
+    S.a_l = a_t; S.f_l = f_t; S.g_l = g_t; return 0;
+  }
+  return 1;
+}
+
+__device__ __forceinline__ void set_trial(AlignState &S, const OptParams &P, bool refresh_h) {
+  S.xt[0] = S.p[0] + S.dir[0] * S.a_t;
+  S.xt[1] = S.p[1] + S.dir[1] * S.a_t;
+  S.xt[2] = S.p[2] + S.dir[2] * S.a_t;
+  S.T = tf_from_p(S.xt);
+  angle_cs(P.snap_thresh, S.xt[2], S.cj, S.sj);
+  if (refresh_h || !P.stale_h_ang) { S.ch = S.cj; S.sh = S.sj; }
+}
+
+// Start (or finish) outer iterations until a derivative pass is needed or the match is done.
+__device__ __noinline__ void begin_outer(AlignState &S, const OptParams &P) {
+  for (;;) {
+    double mg[3] = {-S.g[0], -S.g[1], -S.g[2]}, dp[3];
+    solve3(S.H, mg, dp);
+    double nrm = sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]);
+    if (nrm == 0 || nrm != nrm) { S.converged = (nrm == nrm); S.phase = PH_DONE; return; }
+    S.dir[0] = dp[0] / nrm; S.dir[1] = dp[1] / nrm; S.dir[2] = dp[2] / nrm;
+    S.phi0 = -S.score;
+    S.dphi0 = -(S.g[0] * S.dir[0] + S.g[1] * S.dir[1] + S.g[2] * S.dir[2]);
+    double a = 0.0;
+    bool need_eval = true;
+    if (S.dphi0 >= 0) {
+      if (S.dphi0 == 0) need_eval = false;
+      else { S.dphi0 *= -1; S.dir[0] *= -1; S.dir[1] *= -1; S.dir[2] *= -1; }
+    }
+    if (need_eval) {
+      S.step_iterations = 0;
+      S.a_l = 0; S.a_u = 0;
+      S.f_l = S.phi0 - S.phi0 - P.mt_mu * S.dphi0 * S.a_l;
+      S.g_l = S.dphi0 - P.mt_mu * S.dphi0;
+      S.f_u = S.phi0 - S.phi0 - P.mt_mu * S.dphi0 * S.a_u;
+      S.g_u = S.dphi0 - P.mt_mu * S.dphi0;
+      S.interval_converged = (P.step_size - P.trans_eps / 2) < 0;
+      S.open_interval = 1;
+      double a_t = nrm;
+      a_t = (P.step_size < a_t) ? P.step_size : a_t;
+      a_t = (a_t < P.trans_eps / 2) ? P.trans_eps / 2 : a_t;
+      S.a_t = a_t;
+      set_trial(S, P, true);
+      S.phase = PH_LS_FIRST;
+      return;
+    }
+    // zero directional derivative: step length 0, parameters unchanged
+    int over = P.conv_ge ? (S.iters >= P.max_iter) : (S.iters > P.max_iter);
+    bool conv = over || (S.iters && (fabs(a) < P.trans_eps));
+    S.iters++;
+    if (conv) { S.converged = 1; S.phase = PH_DONE; return; }
+  }
+}
+
+// Consume one derivative pass (score, gradient, Hessian at the current trial transform).
+__device__ __noinline__ void advance(AlignState &S, const OptParams &P, const MapView &M,
+                                     const double tot[kAcc], double *trace, int trace_cap,
+                                     int *trace_rows) {
+  const double w = M.d1 * M.d2;
+  S.score = -M.d1 * tot[0];
+  S.g[0] = w * tot[1]; S.g[1] = w * tot[2]; S.g[2] = w * tot[3];
+  S.H[0] = w * tot[4]; S.H[1] = w * tot[5]; S.H[2] = w * tot[6];
+  S.H[3] = w * tot[7]; S.H[4] = w * tot[8]; S.H[5] = w * tot[9];
+  S.pairs += tot[10];
+  S.evals++; S.ref_evals++;
+  if (trace) {
+    int row = *trace_rows;
+    if (row < trace_cap) {
+      double *t = trace + 8 * (size_t)row;
+      const double *pp = (S.phase == PH_INIT) ? S.p : S.xt;
+      t[0] = (S.phase == PH_INIT) ? 0.0 : S.a_t; t[1] = S.score;
+      t[2] = S.g[0]; t[3] = S.g[1]; t[4] = S.g[2]; t[5] = pp[0]; t[6] = pp[1]; t[7] = pp[2];
+    }
+    *trace_rows = row + 1;
+  }
+  if (S.phase == PH_INIT) { begin_outer(S, P); return; }
+
+  const double mu = P.mt_mu, nu = P.mt_nu;
+  double phi_t = -S.score;
+  double d_phi_t = -(S.g[0] * S.dir[0] + S.g[1] * S.dir[1] + S.g[2] * S.dir[2]);
+  double psi_t = phi_t - S.phi0 - mu * S.dphi0 * S.a_t;
+  double d_psi_t = d_phi_t - mu * S.dphi0;
+  if (S.phase == PH_LS_INNER) {
+    if (S.open_interval && (psi_t <= 0 && d_psi_t >= 0)) {
+      S.open_interval = 0;
+      S.f_l = S.f_l + S.phi0 - mu * S.dphi0 * S.a_l; S.g_l = S.g_l + mu * S.dphi0;
+      S.f_u = S.f_u + S.phi0 - mu * S.dphi0 * S.a_u; S.g_u = S.g_u + mu * S.dphi0;
+    }
+    if (S.open_interval) S.interval_converged = mt_update(S, S.a_t, psi_t, d_psi_t);
+    else                 S.interval_converged = mt_update(S, S.a_t, phi_t, d_phi_t);
+    S.step_iterations++;
+  }
+  bool more = !S.interval_converged && S.step_iterations < P.mt_max_iter &&
+              !(psi_t <= 0 && d_phi_t <= -nu * S.dphi0);
+  if (more) {
+    double a_t;
+    if (S.open_interval) a_t = mt_trial(S.a_l, S.f_l, S.g_l, S.a_u, S.f_u, S.g_u, S.a_t, psi_t, d_psi_t);
+    else                 a_t = mt_trial(S.a_l, S.f_l, S.g_l, S.a_u, S.f_u, S.g_u, S.a_t, phi_t, d_phi_t);
+    a_t = (P.step_size < a_t) ? P.step_size : a_t;
+    a_t = (a_t < P.trans_eps / 2) ? P.trans_eps / 2 : a_t;
+    S.a_t = a_t;
+    set_trial(S, P, false);
+    S.phase = PH_LS_INNER;
+    return;
+  }
+  // line search done.  The reference now runs a Hessian-only pass when the inner loop ran;
+  // the Hessian of the last pass (same cloud, same angle terms) is that Hessian already.
+  if (S.step_iterations) S.ref_evals++;
+  const double a = S.a_t;
+  S.p[0] += S.dir[0] * a; S.p[1] += S.dir[1] * a; S.p[2] += S.dir[2] * a;
+  int over = P.conv_ge ? (S.iters >= P.max_iter) : (S.iters > P.max_iter);
+  bool conv = over || (S.iters && (fabs(a) < P.trans_eps));
+  S.iters++;
+  if (conv) { S.converged = 1; S.phase = PH_DONE; return; }
+  begin_outer(S, P);
+}
+
+__device__ __noinline__ void init_state(AlignState &S, const OptParams &P, const double init[3],
+                                        double n_points) {
+  S.iters = 0; S.evals = 0; S.ref_evals = 0; S.converged = 0; S.step_iterations = 0;
+  S.open_interval = 1; S.interval_converged = 0; S.pairs = 0.0; S.n_points = n_points;
+  double pi[3] = {init[0], init[1], init[2]};
+  S.T = tf_from_p(pi);     // init_guess = Translation3f * AngleAxisf (src/PoseEstimator.cpp:22-24)
+  // p0 = (translation, eulerAngles(0,1,2)) of the float matrix: (-0, 0, atan2f(s, c))
+  S.p[0] = (double)S.T.tx; S.p[1] = (double)S.T.ty;
+  S.p[2] = (double)(float)atan2((double)S.T.s, (double)S.T.c);
+  S.xt[0] = S.p[0]; S.xt[1] = S.p[1]; S.xt[2] = S.p[2];
+  S.dir[0] = S.dir[1] = S.dir[2] = 0.0; S.a_t = 0.0;
+  angle_cs(P.snap_thresh, S.p[2], S.cj, S.sj);
+  S.ch = S.cj; S.sh = S.sj;
+  S.score = 0.0;
+  S.phase = PH_INIT;
+}
+
+// a9: src/PoseEstimator.cpp:31-35 on the float32 entries; asinf/acosf modelled as correctly rounded.
+__device__ __forceinline__ double yaw_from_T(float T00, float T10) {
+  if (T00 > 0 && T10 > 0) return (double)(float)asin((double)T10);
+  if (T00 > 0 && T10 < 0) return (double)(float)asin((double)T10);
+  if (T00 < 0 && T10 > 0) return (double)(float)acos((double)T00);
+  return (double)(float)acos((double)T00) * (-1.0);
+}
+
+// ------------------------------------------------------------------------------------------
+// a7: nearest raw map point by ring search over the voxel buckets (exact, no range cut)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy) {
+  int cx = (int)floorf(qx * M.inv_leaf) - M.min_bx, cy = (int)floorf(qy * M.inv_leaf) - M.min_by;
+  cx = cx < 0 ? 0 : (cx >= M.div_x ? M.div_x - 1 : cx);
+  cy = cy < 0 ? 0 : (cy >= M.div_y ? M.div_y - 1 : cy);
+  float best = INFINITY;
+  const int rmax = M.div_x > M.div_y ? M.div_x : M.div_y;
+  const double L = (double)M.leaf;
+  for (int r = 0; r <= rmax; ++r) {
+    const int y0 = cy - r, y1 = cy + r, x0 = cx - r, x1 = cx + r;
+    for (int yy = (y0 < 0 ? 0 : y0); yy <= y1 && yy < M.div_y; ++yy) {
+      const bool edge = (yy == y0 || yy == y1);
+      if (edge) {
+        // whole row segment [x0, x1]: buckets of consecutive voxels are contiguous
+        int xa = x0 < 0 ? 0 : x0, xb = x1 >= M.div_x ? M.div_x - 1 : x1;
+        if (xa > xb) continue;
+        size_t g = (size_t)yy * M.div_x;
+        for (int s = M.pt_start[g + xa], se = M.pt_start[g + xb + 1]; s < se; ++s) {
+          float2 p = M.pts[s];
+          float ex = qx - p.x, ey = qy - p.y;
+          float dd = ex * ex + ey * ey;
+          best = dd < best ? dd : best;
+        }
+      } else {
+        for (int side = 0; side < 2; ++side) {
+          int xx = side ? x1 : x0;
+          if (xx < 0 || xx >= M.div_x || (side && x1 == x0)) continue;
+          size_t g = (size_t)yy * M.div_x + xx;
+          for (int s = M.pt_start[g], se = M.pt_start[g + 1]; s < se; ++s) {
+            float2 p = M.pts[s];
+            float ex = qx - p.x, ey = qy - p.y;
+            float dd = ex * ex + ey * ey;
+            best = dd < best ? dd : best;
+          }
+        }
+      }
+    }
+    double bound = (double)r * L * 0.999;    // unvisited points are farther than r*L
+    if ((double)best <= bound * bound) break;
+  }
+  return best;
+}
+
+// ------------------------------------------------------------------------------------------
+// the match kernel: one workgroup per scan, the whole optimisation on the device
+// ------------------------------------------------------------------------------------------
+constexpr int kBlock = 1024;
+constexpr int kWaves = kBlock / 64;
+
+__global__ void __launch_bounds__(kBlock)
+ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
+                 const unsigned long long *__restrict__ offsets, int B, int shared_scan,
+                 const double *__restrict__ inits, ndt_result *__restrict__ results,
+                 double *__restrict__ trace, int trace_cap, int *__restrict__ trace_rows) {
+  __shared__ AlignState S;
+  __shared__ double sred[(kWaves + 1) * kAcc];
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
+    const unsigned long long o1 = shared_scan ? offsets[1] : offsets[b + 1];
+    const int n = (int)(o1 - o0);
+    const float2 *scan = reinterpret_cast<const float2 *>(scans) + o0;
+    double *tr = trace ? trace + (size_t)b * trace_cap * 8 : nullptr;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      init_state(S, P, inits + 3 * (size_t)b, (double)n);
+      if (trace_rows) trace_rows[b] = 0;
+      if (n <= 0) { S.phase = PH_DONE; S.converged = 0; }
+    }
+    __syncthreads();
+    // ---- optimisation loop: every iteration is one derivative pass (HOT LOOP A+B fused) ----
+    for (;;) {
+      if (S.phase == PH_DONE) break;
+      const Tf32 T = S.T;
+      const double cj = S.cj, sj = S.sj, ch = S.ch, sh = S.sh;
+      Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+      for (int i = threadIdx.x; i < n; i += kBlock) {
+        float2 pt = scan[i];
+        eval_point(M, T, pt.x, pt.y, cj, sj, ch, sh, A);
+      }
+      double v[kAcc] = {A.e, A.g0, A.g1, A.g2, A.hxx, A.hxy, A.hxt, A.hyy, A.hyt, A.htt, A.pairs};
+      block_reduce<kAcc>(v, sred);
+      if (threadIdx.x == 0) advance(S, P, M, v, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
+      __syncthreads();
+    }
+    // ---- epilogue: fitness score at the final float32 transform (HOT LOOP C) ----
+    const Tf32 T = S.T;
+    double fs[2] = {0.0, 0.0};
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+      float2 pt = scan[i];
+      float qx, qy;
+      tf_apply(T, M.transform_sse, pt.x, pt.y, qx, qy);
+      if (!finite2(qx, qy)) continue;
+      float best = nearest_sq(M, qx, qy);
+      if (best < INFINITY) { fs[0] += (double)best; fs[1] += 1.0; }
+    }
+    block_reduce<2>(fs, sred);
+    if (threadIdx.x == 0) {
+      ndt_result R;
+      R.pose[0] = (double)T.tx; R.pose[1] = (double)T.ty; R.pose[2] = yaw_from_T(T.c, T.s);
+      R.T00 = T.c; R.T10 = T.s; R.T03 = T.tx; R.T13 = T.ty;
+      R.fitness = fs[1] > 0 ? fs[0] / fs[1] : DBL_MAX;
+      R.score = S.score;
+      R.trans_prob = n > 0 ? S.score / (double)n : 0.0;
+      R.H[0] = S.H[0]; R.H[1] = S.H[1]; R.H[2] = S.H[2];
+      R.H[3] = S.H[1]; R.H[4] = S.H[3]; R.H[5] = S.H[4];
+      R.H[6] = S.H[2]; R.H[7] = S.H[4]; R.H[8] = S.H[5];
+      R.p[0] = S.p[0]; R.p[1] = S.p[1]; R.p[2] = S.p[2];
+      R.iters = S.iters; R.evals = S.evals;
+      R.ref_evals = S.ref_evals + 1;       // + the getHessian pass (src/PoseEstimator.cpp:56)
+      R.converged = S.converged;
+      R.status = n > 0 ? NDT_OK : NDT_E_ARG;
+      R.pad_ = 0;
+      R.kbar = (S.evals > 0 && n > 0) ? S.pairs / ((double)S.evals * (double)n) : 0.0;
+      results[b] = R;
+    }
+  }
+}
+
+// One derivative pass at an explicit pose (tests / profiling): grid-stride over points,
+// one partial record per workgroup, summed on the host in block order.
+__global__ void __launch_bounds__(256)
+ndt_eval_kernel(MapView M, double snap, const float *__restrict__ scan, size_t stride, int n,
+                double p0, double p1, double p2, double *__restrict__ partial /* grid x kAcc */) {
+  __shared__ double sred[(4 + 1) * kAcc];
+  double p[3] = {p0, p1, p2};
+  Tf32 T = tf_from_p(p);
+  double cj, sj;
+  angle_cs(snap, p2, cj, sj);
+  Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float2 pt = load_pt(scan, stride, i);
+    eval_point(M, T, pt.x, pt.y, cj, sj, cj, sj, A);
+  }
+  double v[kAcc] = {A.e, A.g0, A.g1, A.g2, A.hxx, A.hxy, A.hxt, A.hyy, A.hyt, A.htt, A.pairs};
+  block_reduce<kAcc>(v, sred);
+  if (threadIdx.x < kAcc) partial[blockIdx.x * kAcc + threadIdx.x] = v[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256)
+ndt_fitness_kernel(MapView M, const float *__restrict__ scan, size_t stride, int n, Tf32 T,
+                   double *__restrict__ partial /* grid x 2 */) {
+  __shared__ double sred[(4 + 1) * 2];
+  double fs[2] = {0.0, 0.0};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float2 pt = load_pt(scan, stride, i);
+    float qx, qy;
+    tf_apply(T, M.transform_sse, pt.x, pt.y, qx, qy);
+    if (!finite2(qx, qy)) continue;
+    float best = nearest_sq(M, qx, qy);
+    if (best < INFINITY) { fs[0] += (double)best; fs[1] += 1.0; }
+  }
+  block_reduce<2>(fs, sred);
+  if (threadIdx.x < 2) partial[blockIdx.x * 2 + threadIdx.x] = fs[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------
+// a2: voxel normal-distributions build
+// ------------------------------------------------------------------------------------------
+
+// order-preserving float <-> uint for atomicMin/atomicMax
+__device__ __forceinline__ unsigned f2ord(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(unsigned u) {
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  f = __uint_as_float(u);
+#else
+  memcpy(&f, &u, 4);
+#endif
+  return f;
+}
+
+// getMinMax3D: bounds[0..3] = ord(min x), ord(min y), ord(max x), ord(max y)
+__global__ void map_minmax_kernel(const float *__restrict__ xy, size_t stride, size_t n,
+                                  unsigned *__restrict__ bounds) {
+  float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float2 p = load_pt(xy, stride, i);
+    if (!finite2(p.x, p.y)) continue;
+    mnx = fminf(mnx, p.x); mxx = fmaxf(mxx, p.x);
+    mny = fminf(mny, p.y); mxy = fmaxf(mxy, p.y);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = fminf(mnx, __shfl_down(mnx, o)); mny = fminf(mny, __shfl_down(mny, o));
+    mxx = fmaxf(mxx, __shfl_down(mxx, o)); mxy = fmaxf(mxy, __shfl_down(mxy, o));
+  }
+  if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
+    atomicMin(&bounds[0], f2ord(mnx)); atomicMin(&bounds[1], f2ord(mny));
+    atomicMax(&bounds[2], f2ord(mxx)); atomicMax(&bounds[3], f2ord(mxy));
+  }
+}
+
+struct GridDims { float inv_leaf; int min_bx, min_by, div_x, div_y, gw, gh; };
+
+__device__ __forceinline__ int voxel_of(const GridDims &G, float2 p) {
+  if (!finite2(p.x, p.y)) return -1;
+  int ix = (int)floorf(p.x * G.inv_leaf) - G.min_bx;
+  int iy = (int)floorf(p.y * G.inv_leaf) - G.min_by;
+  return iy * G.div_x + ix;
+}
+
+__global__ void map_count_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims G,
+                                 int *__restrict__ count) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int v = voxel_of(G, load_pt(xy, stride, i));
+    if (v >= 0) atomicAdd(&count[v], 1);
+  }
+}
+
+// exclusive scan of count[0..ng) into start[0..ng], three small kernels
+constexpr int kScanBlock = 256, kScanPer = 8, kScanTile = kScanBlock * kScanPer;
+
+__global__ void __launch_bounds__(kScanBlock)
+scan_tile_sums_kernel(const int *__restrict__ in, size_t n, int *__restrict__ tile_sum) {
+  __shared__ int sh[kScanBlock / 64];
+  size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPer;
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) if (base + k < n) s += in[base + k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kScanBlock / 64; ++w) t += sh[w]; tile_sum[blockIdx.x] = t; }
+}
+
+__global__ void __launch_bounds__(1024)
+scan_tile_offsets_kernel(int *__restrict__ tile_sum, int ntiles, int *__restrict__ total) {
+  // single workgroup: exclusive scan of the tile sums, in place
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = i < ntiles ? tile_sum[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    int incl = sh[threadIdx.x];
+    if (i < ntiles) tile_sum[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(kScanBlock)
+scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ tile_off,
+                  int *__restrict__ out /* n + 1 */, const int *__restrict__ total) {
+  __shared__ int sh[kScanBlock];
+  size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPer;
+  int v[kScanPer]; int s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < kScanBlock; o <<= 1) {
+    int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int run = tile_off[blockIdx.x] + sh[threadIdx.x] - s;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+}
+
+__global__ void map_scatter_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims G,
+                                   const int *__restrict__ start, int *__restrict__ fill,
+                                   int *__restrict__ perm) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    int v = voxel_of(G, load_pt(xy, stride, i));
+    if (v < 0) continue;
+    int slot = start[v] + atomicAdd(&fill[v], 1);
+    perm[slot] = (int)i;
+  }
+}
+
+// Restore input order inside every bucket (PCL accumulates a voxel's points in cloud order and
+// its float32 centroid sum depends on that order): one wave per voxel, rank by counting.
+__global__ void __launch_bounds__(256)
+map_order_kernel(const int *__restrict__ start, size_t ng, const int *__restrict__ perm,
+                 int *__restrict__ perm_sorted) {
+  size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (g >= ng) return;
+  const int lane = threadIdx.x & 63;
+  const int s0 = start[g], n = start[g + 1] - s0;
+  if (n <= 0) return;
+  if (n == 1) { if (lane == 0) perm_sorted[s0] = perm[s0]; return; }
+  for (int e = lane; e < n; e += 64) {
+    const int mine = perm[s0 + e];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (perm[s0 + j] < mine) ? 1 : 0;
+    perm_sorted[s0 + rank] = mine;
+  }
+}
+
+struct LeafParams { int min_pts, cov_unbiased, cov_init_identity; double eig_mult; };
+
+// Mean, regularised covariance and its inverse of one z = 0 voxel (second loop of
+// VoxelGridCovariance::applyFilter); closed-form 2x2 eigen-decomposition, the z eigenpair is
+// exactly (czz, e_z).  Returns 1 accepted, 0 rejected (icov = 0), -1 rejected with inf icov.
+__device__ int leaf_finalize(const LeafParams &L, int n, double sx, double sy, double sxx,
+                             double sxy, double syy, double szz, double mean[2], double icov[3]) {
+  const double dn = (double)n;
+  const double mx = sx / dn, my = sy / dn;
+  mean[0] = mx; mean[1] = my;
+  icov[0] = icov[1] = icov[2] = 0.0;
+  double cxx, cxy, cyy, czz;
+  if (!L.cov_unbiased) {
+    cxx = (sxx - 2.0 * (sx * mx)) / dn + mx * mx;
+    cxy = (sxy - 2.0 * (sx * my)) / dn + mx * my;
+    cyy = (syy - 2.0 * (sy * my)) / dn + my * my;
+    czz = szz / dn;
+    const double f = (dn - 1.0) / dn;
+    cxx *= f; cxy *= f; cyy *= f; czz *= f;
+  } else {
+    cxx = (sxx - sx * mx) / (dn - 1.0);
+    cxy = (sxy - sx * my) / (dn - 1.0);
+    cyy = (syy - sy * my) / (dn - 1.0);
+    czz = szz / (dn - 1.0);
+  }
+  const double hd = 0.5 * (cxx - cyy), tr = 0.5 * (cxx + cyy);
+  const double rad = sqrt(hd * hd + cxy * cxy);
+  const double l1 = tr - rad, l2 = tr + rad;
+  double vx, vy;
+  if (rad == 0.0) { vx = 1.0; vy = 0.0; }
+  else if (hd >= 0.0) { vx = hd + rad; vy = cxy; }
+  else { vx = cxy; vy = rad - hd; }
+  const double vn = sqrt(vx * vx + vy * vy);
+  if (vn == 0.0) { vx = 1.0; vy = 0.0; } else { vx /= vn; vy /= vn; }
+  // ascending order of {l1, l2, czz}; z first among equals
+  double ev0, ev1, ev2; int k0, k1, k2;   // kind: 0 = l1, 1 = l2, 2 = z
+  if (czz <= l1)      { ev0 = czz; k0 = 2; ev1 = l1; k1 = 0; ev2 = l2; k2 = 1; }
+  else if (czz <= l2) { ev0 = l1; k0 = 0; ev1 = czz; k1 = 2; ev2 = l2; k2 = 1; }
+  else                { ev0 = l1; k0 = 0; ev1 = l2; k1 = 1; ev2 = czz; k2 = 2; }
+  if (ev0 < 0 || ev1 < 0 || ev2 <= 0) return 0;
+  const double thr = L.eig_mult * ev2;
+  bool rebuilt = false;
+  if (ev0 < thr) { ev0 = thr; if (ev1 < thr) ev1 = thr; rebuilt = true; }
+  double n1 = l1, n2 = l2;
+  if (k0 == 0) n1 = ev0; else if (k0 == 1) n2 = ev0;
+  if (k1 == 0) n1 = ev1; else if (k1 == 1) n2 = ev1;
+  if (k2 == 0) n1 = ev2; else if (k2 == 1) n2 = ev2;
+  if (rebuilt) {
+    cxx = n1 * (vy * vy) + n2 * (vx * vx);
+    cxy = -n1 * (vx * vy) + n2 * (vx * vy);
+    cyy = n1 * (vx * vx) + n2 * (vy * vy);
+  }
+  const double det = cxx * cyy - cxy * cxy;
+  icov[0] = cyy / det; icov[1] = -cxy / det; icov[2] = cxx / det;
+  for (int a = 0; a < 3; ++a)
+    if (icov[a] == (double)INFINITY || icov[a] == -(double)INFINITY) return -1;
+  return 1;
+}
+
+// One lane per voxel: sequential sums in cloud order (float32 centroid, fp64 mean / Sxx),
+// bucketed copy of the raw points, cell record.
+__global__ void __launch_bounds__(256)
+map_finalize_kernel(const float *__restrict__ xy, size_t stride, GridDims G, LeafParams L,
+                    const int *__restrict__ start, const int *__restrict__ perm_sorted,
+                    float2 *__restrict__ pts, float2 *__restrict__ cent, double *__restrict__ rec,
+                    int *__restrict__ npts_grid, int *__restrict__ counters /* n_cells, n_valid */) {
+  const size_t ng = (size_t)G.div_x * G.div_y;
+  size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (g >= ng) return;
+  const int s0 = start[g], s1 = start[g + 1], n = s1 - s0;
+  int flag = 0;
+  if (n > 0) {
+    float fx = 0.f, fy = 0.f;
+    double sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0, szz = 0;
+    if (L.cov_init_identity) { sxx = 1.0; syy = 1.0; szz = 1.0; }
+    for (int s = s0; s < s1; ++s) {
+      float2 p = load_pt(xy, stride, (size_t)perm_sorted[s]);
+      pts[s] = p;
+      fx += p.x; fy += p.y;
+      double X = (double)p.x, Y = (double)p.y;
+      sx += X; sy += Y;
+      sxx += X * X; sxy += X * Y; syy += Y * Y;
+    }
+    if (n >= L.min_pts) {
+      const int ix = (int)(g % G.div_x), iy = (int)(g / G.div_x);
+      const size_t pg = (size_t)(iy + 2) * G.gw + (ix + 2);
+      double mean[2], icov[3];
+      int ok = leaf_finalize(L, n, sx, sy, sxx, sxy, syy, szz, mean, icov);
+      cent[pg] = make_float2(fx / (float)n, fy / (float)n);
+      double *r = rec + pg * 8;
+      r[0] = mean[0]; r[1] = mean[1]; r[2] = icov[0]; r[3] = icov[1]; r[4] = icov[2];
+      flag = ok > 0 ? n : -n;
+      atomicAdd(&counters[0], 1);
+      if (ok > 0) atomicAdd(&counters[1], 1);
+    }
+  }
+  npts_grid[g] = flag;
+}
+
+__global__ void fill_f2_kernel(float2 *p, size_t n, float v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = make_float2(v, v);
+}
+
+}  // namespace
+
+// ==========================================================================================
+// host side
+// ==========================================================================================
+
+struct ndt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;       // the stream all work is ordered on
+  hipStream_t own_stream = nullptr;   // created by ndt_ctx_create
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  float map_ms = 0.f, align_ms = 0.f;
+  // grow-only staging for the host-pointer entry points
+  void *d_scan = nullptr; size_t d_scan_cap = 0;
+  void *d_off = nullptr; size_t d_off_cap = 0;
+  void *d_init = nullptr; size_t d_init_cap = 0;
+  void *d_res = nullptr; size_t d_res_cap = 0;
+  void *d_tmp = nullptr; size_t d_tmp_cap = 0;
+  void *d_trace = nullptr; size_t d_trace_cap = 0;
+  void *d_rows = nullptr; size_t d_rows_cap = 0;
+};
+
+struct ndt_map {
+  ndt_ctx *ctx = nullptr;
+  ndt_params prm;
+  ndt_map_info info;
+  bool info_valid = false;
+  MapView view;
+  size_t n = 0, ng = 0, npad = 0;
+  // device buffers (grow-only across rebuilds)
+  int *count = nullptr, *start = nullptr, *fill = nullptr, *tile = nullptr, *npts_grid = nullptr;
+  size_t count_cap = 0, start_cap = 0, fill_cap = 0, tile_cap = 0, npts_cap = 0;
+  int *perm = nullptr, *perm_sorted = nullptr; float2 *pts = nullptr;
+  size_t perm_cap = 0, perm_sorted_cap = 0, pts_cap = 0;
+  float2 *cent = nullptr; double *rec = nullptr; size_t cent_cap = 0, rec_cap = 0;
+  unsigned *bounds = nullptr; int *counters = nullptr; int *total = nullptr;
+  void *d_xy_stage = nullptr; size_t d_xy_cap = 0;
+};
+
+namespace {
+
+int fail(ndt_ctx *ctx, int code, const std::string &msg) {
+  g_last_error = msg;
+  if (ctx) ctx->err = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail((ctx), NDT_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+  } while (0)
+
+int ensure(ndt_ctx *ctx, void **p, size_t *cap, size_t need) {
+  if (need <= *cap && *p) return NDT_OK;
+  if (*p) { hipError_t e = hipFree(*p); (void)e; *p = nullptr; *cap = 0; }
+  size_t want = need + need / 4 + 256;
+  HIP_TRY(ctx, hipMalloc(p, want));
+  *cap = want;
+  return NDT_OK;
+}
+
+template <typename T>
+int ensure_t(ndt_ctx *ctx, T **p, size_t *cap_elems, size_t need_elems) {
+  size_t cap_bytes = *cap_elems * sizeof(T);
+  void *vp = *p;
+  int rc = ensure(ctx, &vp, &cap_bytes, need_elems * sizeof(T));
+  *p = static_cast<T *>(vp);
+  *cap_elems = cap_bytes / sizeof(T);
+  return rc;
+}
+
+OptParams opt_of(const ndt_params &p) {
+  OptParams o;
+  o.step_size = p.step_size; o.trans_eps = p.trans_eps; o.snap_thresh = p.snap_thresh;
+  o.mt_mu = p.mt_mu; o.mt_nu = p.mt_nu; o.max_iter = p.max_iter; o.conv_ge = p.conv_ge;
+  o.stale_h_ang = p.stale_h_ang; o.mt_max_iter = p.mt_max_iter;
+  return o;
+}
+
+// a3: Gaussian constants (Magnusson 2009 eq 6.8), host libm, once per map.
+void gauss_constants(const ndt_params &p, double *d1, double *d2) {
+  double res = (double)p.resolution;
+  double c1 = 10.0 * (1.0 - p.outlier_ratio);
+  double c2 = p.outlier_ratio / std::pow(res, 3);
+  double d3 = -std::log(c2);
+  *d1 = -std::log(c1 + c2) - d3;
+  *d2 = -2.0 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / *d1);
+}
+
+int grid_for(size_t n, int block, int cap = 2048) {
+  size_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > (size_t)cap) g = cap;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ndt_default_params(ndt_params *p) {
+  if (!p) return NDT_E_ARG;
+  memset(p, 0, sizeof(*p));
+  p->resolution = 1.0f; p->step_size = 0.1; p->trans_eps = 0.01; p->max_iter = 35;
+  p->outlier_ratio = 0.55; p->min_pts = 6; p->eig_mult = 0.01;
+  p->cov_unbiased = 0; p->cov_init_identity = 0; p->conv_ge = 0; p->radius_inclusive = 0;
+  p->transform_sse = 0; p->stale_h_ang = 1; p->snap_thresh = 10e-5; p->mt_max_iter = 10;
+  p->mt_mu = 1.e-4; p->mt_nu = 0.9;
+  return NDT_OK;
+}
+
+const char *ndt_last_error(const ndt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int ndt_ctx_create(int device, ndt_ctx **out) {
+  if (!out) return NDT_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, NDT_E_NO_DEVICE, "no HIP device visible: libndt_mi355x has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(nullptr, NDT_E_ARG, "device ordinal out of range");
+  ndt_ctx *c = new (std::nothrow) ndt_ctx();
+  if (!c) return NDT_E_NOMEM;
+  c->device = device;
+  HIP_TRY(c, hipSetDevice(device));
+  HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+  c->stream = c->own_stream;
+  HIP_TRY(c, hipEventCreate(&c->ev0));
+  HIP_TRY(c, hipEventCreate(&c->ev1));
+  *out = c;
+  return NDT_OK;
+}
+
+int ndt_ctx_destroy(ndt_ctx *c) {
+  if (!c) return NDT_E_ARG;
+  hipError_t e;
+  e = hipSetDevice(c->device);
+  e = hipStreamSynchronize(c->stream);
+  if (c->own_stream) e = hipStreamDestroy(c->own_stream);
+  if (c->ev0) e = hipEventDestroy(c->ev0);
+  if (c->ev1) e = hipEventDestroy(c->ev1);
+  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows};
+  for (void *b : bufs) if (b) e = hipFree(b);
+  (void)e;
+  delete c;
+  return NDT_OK;
+}
+
+void *ndt_ctx_stream(ndt_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int ndt_ctx_set_stream(ndt_ctx *c, void *stream) {
+  if (!c) return NDT_E_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->stream = stream ? (hipStream_t)stream : c->own_stream;
+  return NDT_OK;
+}
+
+int ndt_last_timing(const ndt_ctx *c, float *map_ms, float *align_ms) {
+  if (!c) return NDT_E_ARG;
+  if (map_ms) *map_ms = c->map_ms;
+  if (align_ms) *align_ms = c->align_ms;
+  return NDT_OK;
+}
+
+int ndt_map_destroy(ndt_map *m) {
+  if (!m) return NDT_E_ARG;
+  hipError_t e = hipSetDevice(m->ctx->device);
+  e = hipStreamSynchronize(m->ctx->stream);
+  void *bufs[] = {m->count, m->start, m->fill, m->tile, m->npts_grid, m->perm, m->perm_sorted, m->pts,
+                  m->cent, m->rec, m->bounds, m->counters, m->total, m->d_xy_stage};
+  for (void *b : bufs) if (b) e = hipFree(b);
+  (void)e;
+  delete m;
+  return NDT_OK;
+}
+
+int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, const ndt_params *prm,
+                      ndt_map **pmap) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!xy || n == 0 || !prm || !pmap || !(prm->resolution > 0) || stride < 8 || (stride & 7))
+    return fail(ctx, NDT_E_ARG, "ndt_map_build: bad arguments (need n > 0, resolution > 0, stride % 8 == 0)");
+  if (n > (size_t)INT32_MAX) return fail(ctx, NDT_E_ARG, "ndt_map_build: more than 2^31 points");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  ndt_map *m = *pmap;
+  if (!m) {
+    m = new (std::nothrow) ndt_map();
+    if (!m) return NDT_E_NOMEM;
+    m->ctx = ctx;
+    HIP_TRY(ctx, hipMalloc(&m->bounds, 4 * sizeof(unsigned)));
+    HIP_TRY(ctx, hipMalloc(&m->counters, 2 * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc(&m->total, sizeof(int)));
+    *pmap = m;
+  }
+  m->prm = *prm; m->n = n; m->info_valid = false;
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+
+  // 1. bounding box (getMinMax3D)
+  unsigned init_b[4] = {0xffffffffu, 0xffffffffu, 0u, 0u};
+  HIP_TRY(ctx, hipMemcpyAsync(m->bounds, init_b, sizeof(init_b), hipMemcpyHostToDevice, st));
+  map_minmax_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, m->bounds);
+  unsigned hb[4];
+  HIP_TRY(ctx, hipMemcpyAsync(hb, m->bounds, sizeof(hb), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (hb[0] == 0xffffffffu) return fail(ctx, NDT_E_ARG, "ndt_map_build: no finite points");
+  const float inv_leaf = 1.0f / prm->resolution;
+  const float mnx = ord2f(hb[0]), mny = ord2f(hb[1]), mxx = ord2f(hb[2]), mxy = ord2f(hb[3]);
+  GridDims G;
+  G.inv_leaf = inv_leaf;
+  G.min_bx = (int)floorf(mnx * inv_leaf); G.min_by = (int)floorf(mny * inv_leaf);
+  long long dx = (long long)(int)floorf(mxx * inv_leaf) - G.min_bx + 1;
+  long long dy = (long long)(int)floorf(mxy * inv_leaf) - G.min_by + 1;
+  if (dx * dy > (1LL << 28)) return fail(ctx, NDT_E_GRID, "ndt_map_build: voxel grid larger than 2^28 cells");
+  G.div_x = (int)dx; G.div_y = (int)dy; G.gw = G.div_x + 4; G.gh = G.div_y + 4;
+  const size_t ng = (size_t)dx * dy, npad = (size_t)G.gw * G.gh;
+  m->ng = ng; m->npad = npad;
+
+  // 2. buffers (grow-only across rebuilds)
+  {
+    int rc;
+    const size_t ntiles_ = (ng + kScanTile - 1) / kScanTile;
+    if ((rc = ensure_t(ctx, &m->count, &m->count_cap, ng + 1))) return rc;
+    if ((rc = ensure_t(ctx, &m->start, &m->start_cap, ng + 1))) return rc;
+    if ((rc = ensure_t(ctx, &m->fill, &m->fill_cap, ng + 1))) return rc;
+    if ((rc = ensure_t(ctx, &m->npts_grid, &m->npts_cap, ng + 1))) return rc;
+    if ((rc = ensure_t(ctx, &m->tile, &m->tile_cap, ntiles_ + 1))) return rc;
+    if ((rc = ensure_t(ctx, &m->perm, &m->perm_cap, n))) return rc;
+    if ((rc = ensure_t(ctx, &m->perm_sorted, &m->perm_sorted_cap, n))) return rc;
+    if ((rc = ensure_t(ctx, &m->pts, &m->pts_cap, n))) return rc;
+    if ((rc = ensure_t(ctx, &m->cent, &m->cent_cap, npad))) return rc;
+    if ((rc = ensure_t(ctx, &m->rec, &m->rec_cap, npad * 8))) return rc;
+  }
+  HIP_TRY(ctx, hipMemsetAsync(m->count, 0, (ng + 1) * sizeof(int), st));
+  HIP_TRY(ctx, hipMemsetAsync(m->fill, 0, (ng + 1) * sizeof(int), st));
+  HIP_TRY(ctx, hipMemsetAsync(m->counters, 0, 2 * sizeof(int), st));
+  HIP_TRY(ctx, hipMemsetAsync(m->rec, 0, npad * 8 * sizeof(double), st));
+  fill_f2_kernel<<<grid_for(npad, 256), 256, 0, st>>>(m->cent, npad, INFINITY);
+
+  // 3. bucket the points by voxel, cloud order kept inside a bucket
+  map_count_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, m->count);
+  const int ntiles = (int)((ng + kScanTile - 1) / kScanTile);
+  scan_tile_sums_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile);
+  scan_tile_offsets_kernel<<<1, 1024, 0, st>>>(m->tile, ntiles, m->total);
+  scan_apply_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, m->start, m->total);
+  map_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, m->start, m->fill, m->perm);
+  map_order_kernel<<<(unsigned)((ng + 3) / 4), 256, 0, st>>>(m->start, ng, m->perm, m->perm_sorted);
+
+  // 4. per-voxel statistics -> centroid grid + cell records + bucketed raw points
+  LeafParams L;
+  L.min_pts = prm->min_pts; L.cov_unbiased = prm->cov_unbiased; L.cov_init_identity = prm->cov_init_identity;
+  L.eig_mult = prm->eig_mult;
+  map_finalize_kernel<<<(unsigned)((ng + 255) / 256), 256, 0, st>>>(xy, stride, G, L, m->start, m->perm_sorted,
+                                                                    m->pts, m->cent, m->rec, m->npts_grid,
+                                                                    m->counters);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+
+  MapView &V = m->view;
+  V.inv_leaf = inv_leaf; V.leaf = prm->resolution;
+  V.r2 = (float)((double)prm->resolution * (double)prm->resolution);
+  V.radius_inclusive = prm->radius_inclusive; V.transform_sse = prm->transform_sse;
+  V.min_bx = G.min_bx; V.min_by = G.min_by; V.div_x = G.div_x; V.div_y = G.div_y; V.gw = G.gw; V.gh = G.gh;
+  V.cent = m->cent; V.rec = m->rec; V.pt_start = m->start; V.pts = m->pts;
+  gauss_constants(*prm, &V.d1, &V.d2);
+  m->info.min_bx = G.min_bx; m->info.min_by = G.min_by; m->info.div_x = G.div_x; m->info.div_y = G.div_y;
+  m->info.n_points = n;
+  HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
+  HIP_TRY(ctx, hipEventElapsedTime(&ctx->map_ms, ctx->ev0, ctx->ev1));
+  return NDT_OK;
+}
+
+int ndt_map_build(ndt_ctx *ctx, const float *xy_host, size_t n, size_t stride, const ndt_params *prm,
+                  ndt_map **pmap) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!xy_host || n == 0 || !pmap || stride < 8 || (stride & 7)) return fail(ctx, NDT_E_ARG, "ndt_map_build: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  // stage through a buffer owned by the map once it exists; first build uses a temporary
+  void *stage = nullptr; size_t cap = 0;
+  if (*pmap) { stage = (*pmap)->d_xy_stage; cap = (*pmap)->d_xy_cap; }
+  int rc = ensure(ctx, &stage, &cap, n * stride);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(stage, xy_host, n * stride, hipMemcpyHostToDevice, ctx->stream));
+  rc = ndt_map_build_dev(ctx, (const float *)stage, n, stride, prm, pmap);
+  if (*pmap) { (*pmap)->d_xy_stage = stage; (*pmap)->d_xy_cap = cap; }
+  else { hipError_t e = hipFree(stage); (void)e; }
+  return rc;
+}
+
+int ndt_map_info_get(const ndt_map *cm, ndt_map_info *out) {
+  if (!cm || !out) return NDT_E_ARG;
+  ndt_map *m = const_cast<ndt_map *>(cm);
+  if (!m->info_valid) {
+    int c[2];
+    HIP_TRY(m->ctx, hipSetDevice(m->ctx->device));
+    HIP_TRY(m->ctx, hipMemcpyAsync(c, m->counters, sizeof(c), hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_TRY(m->ctx, hipStreamSynchronize(m->ctx->stream));
+    m->info.n_cells = c[0]; m->info.n_valid = c[1];
+    m->info_valid = true;
+  }
+  *out = m->info;
+  return NDT_OK;
+}
+
+int ndt_map_export(const ndt_map *cm, int *cell_idx, float *cent_xy, double *mean_xy, double *icov,
+                   int *npts) {
+  if (!cm || !cell_idx || !cent_xy || !mean_xy || !icov || !npts) return NDT_E_ARG;
+  ndt_map *m = const_cast<ndt_map *>(cm);
+  ndt_ctx *ctx = m->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t ng = m->ng, npad = m->npad;
+  int *hn = (int *)malloc(ng * sizeof(int));
+  float2 *hc = (float2 *)malloc(npad * sizeof(float2));
+  double *hr = (double *)malloc(npad * 8 * sizeof(double));
+  if (!hn || !hc || !hr) { free(hn); free(hc); free(hr); return NDT_E_NOMEM; }
+  hipError_t e1 = hipMemcpyAsync(hn, m->npts_grid, ng * sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipMemcpyAsync(hc, m->cent, npad * sizeof(float2), hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e3 = hipMemcpyAsync(hr, m->rec, npad * 8 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e4 = hipStreamSynchronize(ctx->stream);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+    free(hn); free(hc); free(hr);
+    return fail(ctx, NDT_E_HIP, "ndt_map_export: copy failed");
+  }
+  size_t k = 0;
+  const int gw = m->view.gw, dx = m->view.div_x;
+  for (size_t g = 0; g < ng; ++g) {
+    if (hn[g] == 0) continue;
+    size_t pg = (size_t)(g / dx + 2) * gw + (g % dx + 2);
+    cell_idx[k] = (int)g; npts[k] = hn[g];
+    cent_xy[2 * k] = hc[pg].x; cent_xy[2 * k + 1] = hc[pg].y;
+    mean_xy[2 * k] = hr[pg * 8]; mean_xy[2 * k + 1] = hr[pg * 8 + 1];
+    icov[3 * k] = hr[pg * 8 + 2]; icov[3 * k + 1] = hr[pg * 8 + 3]; icov[3 * k + 2] = hr[pg * 8 + 4];
+    ++k;
+  }
+  free(hn); free(hc); free(hr);
+  return NDT_OK;
+}
+
+int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, const uint64_t *offsets,
+                        int B, int shared_scan, const double *inits, ndt_result *out, void *stream) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!map || !scans || !offsets || !inits || !out || B <= 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  ndt_align_kernel<<<B, kBlock, 0, st>>>(map->view, opt_of(map->prm), scans,
+                                         (const unsigned long long *)offsets, B, shared_scan, inits, out,
+                                         nullptr, 0, nullptr);
+  HIP_TRY(ctx, hipGetLastError());
+  return NDT_OK;
+}
+
+int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, const uint64_t *offsets,
+                          int B, int shared_scan, const double *inits, ndt_result *out, double *trace,
+                          int trace_cap, int *trace_rows) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!map || !scans || !offsets || !inits || !out || B <= 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const size_t nscan = shared_scan ? 1 : (size_t)B;
+  const size_t npts = (size_t)(offsets[nscan] - offsets[0]);
+  if (npts == 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: empty scans");
+  for (size_t b = 0; b < nscan; ++b)
+    if (offsets[b + 1] < offsets[b]) return fail(ctx, NDT_E_ARG, "ndt_align_batch: offsets not monotone");
+  int rc;
+  if ((rc = ensure(ctx, &ctx->d_scan, &ctx->d_scan_cap, (size_t)offsets[nscan] * 8))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_off, &ctx->d_off_cap, (nscan + 1) * 8))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_init, &ctx->d_init_cap, (size_t)B * 24))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_res, &ctx->d_res_cap, (size_t)B * sizeof(ndt_result)))) return rc;
+  double *d_trace = nullptr; int *d_rows = nullptr;
+  if (trace && trace_cap > 0 && trace_rows) {
+    if ((rc = ensure(ctx, &ctx->d_trace, &ctx->d_trace_cap, (size_t)B * trace_cap * 64))) return rc;
+    if ((rc = ensure(ctx, &ctx->d_rows, &ctx->d_rows_cap, (size_t)B * 4))) return rc;
+    d_trace = (double *)ctx->d_trace; d_rows = (int *)ctx->d_rows;
+    HIP_TRY(ctx, hipMemsetAsync(d_trace, 0, (size_t)B * trace_cap * 64, st));
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scan, scans, (size_t)offsets[nscan] * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off, offsets, (nscan + 1) * 8, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_init, inits, (size_t)B * 24, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+  ndt_align_kernel<<<B, kBlock, 0, st>>>(map->view, opt_of(map->prm), (const float *)ctx->d_scan,
+                                         (const unsigned long long *)ctx->d_off, B, shared_scan,
+                                         (const double *)ctx->d_init, (ndt_result *)ctx->d_res, d_trace,
+                                         trace_cap, d_rows);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+  HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_res, (size_t)B * sizeof(ndt_result), hipMemcpyDeviceToHost, st));
+  if (d_trace) {
+    HIP_TRY(ctx, hipMemcpyAsync(trace, d_trace, (size_t)B * trace_cap * 64, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(trace_rows, d_rows, (size_t)B * 4, hipMemcpyDeviceToHost, st));
+  }
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  HIP_TRY(ctx, hipEventElapsedTime(&ctx->align_ms, ctx->ev0, ctx->ev1));
+  return NDT_OK;
+}
+
+int ndt_align_batch(ndt_ctx *ctx, const ndt_map *map, const float *scans, const uint64_t *offsets, int B,
+                    int shared_scan, const double *inits, ndt_result *out) {
+  return ndt_align_batch_trace(ctx, map, scans, offsets, B, shared_scan, inits, out, nullptr, 0, nullptr);
+}
+
+int ndt_align(ndt_ctx *ctx, const ndt_map *map, const float *scan, size_t n, size_t stride,
+              const double init[3], ndt_result *out) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!map || !scan || n == 0 || !init || !out || stride < 8) return fail(ctx, NDT_E_ARG, "ndt_align: bad arguments");
+  const float *packed = scan;
+  float *tmp = nullptr;
+  if (stride != 8) {   // repack pcl::PointXYZ-style records to float2
+    tmp = (float *)malloc(n * 8);
+    if (!tmp) return NDT_E_NOMEM;
+    for (size_t i = 0; i < n; ++i) {
+      const float *p = (const float *)((const char *)scan + i * stride);
+      tmp[2 * i] = p[0]; tmp[2 * i + 1] = p[1];
+    }
+    packed = tmp;
+  }
+  uint64_t off[2] = {0, (uint64_t)n};
+  int rc = ndt_align_batch(ctx, map, packed, off, 1, 0, init, out);
+  free(tmp);
+  return rc;
+}
+
+int ndt_eval_at(ndt_ctx *ctx, const ndt_map *map, const float *scan, size_t n, size_t stride,
+                const double p[3], double *score, double g[3], double H[9], double *pairs) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!map || !scan || n == 0 || !p || stride < 8 || (stride & 7)) return fail(ctx, NDT_E_ARG, "ndt_eval_at: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  const int grid = grid_for(n, 256, 1024);
+  if ((rc = ensure(ctx, &ctx->d_scan, &ctx->d_scan_cap, n * stride))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_tmp, &ctx->d_tmp_cap, (size_t)grid * kAcc * 8))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scan, scan, n * stride, hipMemcpyHostToDevice, st));
+  ndt_eval_kernel<<<grid, 256, 0, st>>>(map->view, map->prm.snap_thresh, (const float *)ctx->d_scan, stride,
+                                        (int)n, p[0], p[1], p[2], (double *)ctx->d_tmp);
+  HIP_TRY(ctx, hipGetLastError());
+  double *hp = (double *)malloc((size_t)grid * kAcc * 8);
+  if (!hp) return NDT_E_NOMEM;
+  hipError_t e = hipMemcpyAsync(hp, ctx->d_tmp, (size_t)grid * kAcc * 8, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { free(hp); return fail(ctx, NDT_E_HIP, hipGetErrorString(e)); }
+  double t[kAcc] = {0};
+  for (int b = 0; b < grid; ++b) for (int k = 0; k < kAcc; ++k) t[k] += hp[b * kAcc + k];
+  free(hp);
+  const double w = map->view.d1 * map->view.d2;
+  if (score) *score = -map->view.d1 * t[0];
+  if (g) { g[0] = w * t[1]; g[1] = w * t[2]; g[2] = w * t[3]; }
+  if (H) {
+    H[0] = w * t[4]; H[1] = H[3] = w * t[5]; H[2] = H[6] = w * t[6];
+    H[4] = w * t[7]; H[5] = H[7] = w * t[8]; H[8] = w * t[9];
+  }
+  if (pairs) *pairs = t[10];
+  return NDT_OK;
+}
+
+int ndt_fitness_at(ndt_ctx *ctx, const ndt_map *map, const float *scan, size_t n, size_t stride,
+                   float c, float s, float tx, float ty, double *fitness) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!map || !scan || n == 0 || !fitness || stride < 8 || (stride & 7)) return fail(ctx, NDT_E_ARG, "ndt_fitness_at: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  const int grid = grid_for(n, 256, 1024);
+  if ((rc = ensure(ctx, &ctx->d_scan, &ctx->d_scan_cap, n * stride))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_tmp, &ctx->d_tmp_cap, (size_t)grid * 16))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scan, scan, n * stride, hipMemcpyHostToDevice, st));
+  Tf32 T = {c, s, tx, ty};
+  ndt_fitness_kernel<<<grid, 256, 0, st>>>(map->view, (const float *)ctx->d_scan, stride, (int)n, T,
+                                           (double *)ctx->d_tmp);
+  HIP_TRY(ctx, hipGetLastError());
+  double *hp = (double *)malloc((size_t)grid * 16);
+  if (!hp) return NDT_E_NOMEM;
+  hipError_t e = hipMemcpyAsync(hp, ctx->d_tmp, (size_t)grid * 16, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) { free(hp); return fail(ctx, NDT_E_HIP, hipGetErrorString(e)); }
+  double sum = 0, cnt = 0;
+  for (int b = 0; b < grid; ++b) { sum += hp[2 * b]; cnt += hp[2 * b + 1]; }
+  free(hp);
+  *fitness = cnt > 0 ? sum / cnt : DBL_MAX;
+  return NDT_OK;
+}
+
+}  // extern "C"

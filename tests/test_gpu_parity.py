@@ -1,0 +1,261 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Tolerance from BASELINE.json north_star: estimated poses within 1e-4 m / 1e-4 rad of the
+CPU path; integer / float32 quantities (voxel membership, centroids, iteration and evaluation
+counts, the float32 final matrix) must match exactly."""
+import math
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL_M = 1e-4      # north_star: 1e-4 m
+POSE_TOL_RAD = 1e-4    # north_star: 1e-4 rad
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a real MI355X"
+    from ndt_slam_amd import capi
+    return capi, capi.Context(0)
+
+
+def wrap(a):
+    return (a + math.pi) % (2 * math.pi) - math.pi
+
+
+def assert_result_parity(r, ref, exact_path=True):
+    assert int(r["status"]) == 0
+    assert int(r["converged"]) == int(ref["converged"])
+    d = r["pose"] - ref["pose"]
+    assert abs(d[0]) <= POSE_TOL_M and abs(d[1]) <= POSE_TOL_M and abs(wrap(d[2])) <= POSE_TOL_RAD
+    if exact_path:
+        assert int(r["iters"]) == int(ref["iters"])
+        assert int(r["ref_evals"]) == int(ref["ref_evals"])
+        assert (r["T00"], r["T10"], r["T03"], r["T13"]) == (ref["T00"], ref["T10"], ref["T03"], ref["T13"])
+        assert r["fitness"] == pytest.approx(ref["fitness"], rel=1e-12)
+        assert r["score"] == pytest.approx(ref["score"], rel=1e-9)
+        assert r["kbar"] * r["evals"] == pytest.approx(ref["kbar"] * ref["evals"], rel=1e-12)
+        Hs = np.abs(ref["H"]).max()
+        assert r["H"] == pytest.approx(ref["H"], rel=1e-8, abs=1e-9 * Hs)
+
+
+# ------------------------------------------------------------------------------------------ a2
+@pytest.mark.parametrize("kw", [dict(), dict(cov_unbiased=1), dict(cov_init_identity=1)])
+def test_map_build_matches_oracle_bit_for_bit(gpu, oracle, c1_world, kw):
+    capi, ctx = gpu
+    m, _, cfg = c1_world
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"], **kw))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"], **kw))
+    gi, oi = gm.info(), om.info()
+    assert (gi.min_bx, gi.min_by, gi.div_x, gi.div_y, gi.n_cells, gi.n_valid) == \
+           (oi.min_bx, oi.min_by, oi.div_x, oi.div_y, oi.n_cells, oi.n_valid)
+    g, o = gm.export(), om.export()
+    assert np.array_equal(g["idx"], o["idx"]) and np.array_equal(g["npts"], o["npts"])
+    assert np.array_equal(g["cent"], o["cent"])            # float32 sums in cloud order
+    assert np.array_equal(g["mean"], o["mean"])            # fp64 sums in cloud order
+    assert g["icov"] == pytest.approx(o["icov"], rel=1e-12, abs=1e-300)
+
+
+def test_map_build_ragged_inputs(gpu, oracle):
+    capi, ctx = gpu
+    rng = np.random.default_rng(5)
+    # one dense voxel (hundreds of points), a sparse one, a rejected one, NaN points, a lone outlier
+    dense = rng.uniform(0.01, 0.99, size=(700, 2))
+    sparse = rng.uniform(3.01, 3.99, size=(4, 2))
+    flat = np.tile([[5.5, 5.5]], (9, 1))
+    pts = np.concatenate([dense, sparse, flat, [[np.nan, 1.0]], [[-40.25, 17.5]]]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    gm = capi.Map(ctx, pts, capi.default_params(resolution=1.0))
+    om = oracle.Map(pts, oracle.default_params(resolution=1.0))
+    g, o = gm.export(), om.export()
+    for k in ("idx", "npts", "cent", "mean"):
+        assert np.array_equal(g[k], o[k]), k
+    assert g["icov"] == pytest.approx(o["icov"], rel=1e-12, abs=1e-300)
+    assert sorted(g["npts"].tolist()) == [-9, 700]
+
+
+def test_map_rebuild_in_place(gpu, oracle, c1_world):
+    capi, ctx = gpu
+    m, _, cfg = c1_world
+    gm = capi.Map(ctx, m[:2000], capi.default_params(resolution=cfg["resolution"]))
+    gm.rebuild(xy=m)                       # bigger cloud into the same handle
+    o = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"])).export()
+    g = gm.export()
+    assert np.array_equal(g["idx"], o["idx"]) and np.array_equal(g["cent"], o["cent"])
+
+
+# ------------------------------------------------------------------------------------------ a4 + a5
+def test_single_evaluation_matches_oracle(gpu, oracle, c1_world):
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    for k in range(4):
+        scan, truth, init = sf.make(k)
+        for p in (init, truth, [truth[0], truth[1], 5e-5], [30.0, 30.0, 0.3]):
+            s, g, H, pairs = gm.eval_at(scan, p)
+            s0, g0, H0, pairs0 = om.eval_at(scan, p)
+            assert pairs == pairs0                              # same neighbour sets
+            assert s == pytest.approx(s0, rel=1e-12, abs=1e-300)
+            assert g == pytest.approx(g0, rel=1e-9, abs=1e-10 * (np.abs(g0).max() + 1e-300))
+            assert H == pytest.approx(H0, rel=1e-9, abs=1e-10 * (np.abs(H0).max() + 1e-300))
+
+
+# ------------------------------------------------------------------------------------------ a7
+def test_fitness_matches_oracle(gpu, oracle, c1_world):
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    scan, truth, init = sf.make(1)
+    for p in (truth, init, [truth[0] + 2.5, truth[1] - 1.5, truth[2] + 0.4], [150.0, -90.0, 1.0]):
+        c, s = np.float32(math.cos(p[2])), np.float32(math.sin(p[2]))
+        tx, ty = np.float32(p[0]), np.float32(p[1])
+        assert gm.fitness_at(scan, c, s, tx, ty) == pytest.approx(om.fitness(scan, c, s, tx, ty), rel=1e-13)
+
+
+# ------------------------------------------------------------------------------------------ a3-a9
+def test_c1_matches_oracle_with_same_step_sequence(gpu, oracle, c1_world):
+    """BASELINE.json configs[0]: 360-pt scan vs 5k-pt map, launch-file parameters."""
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    scans, off, truths, inits = sf.batch(0, 24)
+    res, traces = gm.align_batch(scans, off, inits, trace_cap=512)
+    for b in range(24):
+        scan = scans[int(off[b]):int(off[b + 1])]
+        ref, tr = om.align(scan, inits[b], trace_cap=512)
+        assert_result_parity(res[b], ref)
+        assert len(traces[b]) == len(tr)
+        assert traces[b][:, 0] == pytest.approx(tr[:, 0], rel=1e-8, abs=1e-12)     # step lengths
+        assert traces[b][:, 1] == pytest.approx(tr[:, 1], rel=1e-10)               # scores
+        single = gm.align(scan, inits[b])
+        assert single.tobytes() == res[b].tobytes()                                # batch == single, deterministic
+
+
+def test_yaw_strata_near_90_and_180(gpu, oracle, c1_world):
+    """a9: the asin/acos extraction near +-90 / +-180 deg must follow the same float32 branches."""
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    idx = [5, 13, 21, 29, 37, 45]          # ScanFactory puts these within 0.5 deg of +-90 / +-180
+    for k in idx:
+        scan, truth, init = sf.make(k)
+        r = gm.align(scan, init)
+        ref = om.align(scan, init)
+        assert r["pose"][2] == ref["pose"][2]
+        assert_result_parity(r, ref)
+
+
+@pytest.mark.parametrize("kw", [dict(transform_sse=1), dict(stale_h_ang=0), dict(conv_ge=1, max_iter=3),
+                                dict(radius_inclusive=1), dict(cov_init_identity=1), dict(step_size=0.05, trans_eps=0.02)])
+def test_version_switches_follow_the_oracle(gpu, oracle, c1_world, kw):
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"], **kw))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"], **kw))
+    for k in (0, 3, 4):
+        scan, truth, init = sf.make(k)
+        assert_result_parity(gm.align(scan, init), om.align(scan, init))
+
+
+def test_c2_sized_batch_matches_oracle(gpu, oracle):
+    """10k-pt scans vs a 1M-pt map at 0.5 m (BASELINE.json configs[1]/[2], a 12-scan sample)."""
+    capi, ctx = gpu
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C2"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    g, o = gm.export(), om.export()
+    assert np.array_equal(g["idx"], o["idx"]) and np.array_equal(g["cent"], o["cent"])
+    assert np.array_equal(g["mean"], o["mean"])
+    scans, off, truths, inits = sf.batch(0, 12)
+    res = gm.align_batch(scans, off, inits)
+    ref = om.align_batch(scans, off, inits, nthreads=4)
+    for b in range(12):
+        assert_result_parity(res[b], ref[b])
+
+
+def test_full_size_batch_properties(gpu, oracle):
+    """256 x 10k vs 1M (configs[2]) through size-independent properties: determinism, batch ==
+    shards, recovery of the known transform for well-conditioned scans, and a checksum against
+    the oracle on a strided sample."""
+    capi, ctx = gpu
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C3"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    scans, off, truths, inits = sf.batch(0, 256)
+    r1 = gm.align_batch(scans, off, inits)
+    r2 = gm.align_batch(scans, off, inits)
+    assert r1.tobytes() == r2.tobytes()                                   # deterministic
+    half = gm.align_batch(scans[:int(off[128])], off[:129], inits[:128])
+    assert half.tobytes() == r1[:128].tobytes()                           # sharding invariant
+    err = r1["pose"] - truths
+    err[:, 2] = wrap(err[:, 2])
+    good = (np.abs(err[:, 0]) < 0.02) & (np.abs(err[:, 1]) < 0.02) & (np.abs(err[:, 2]) < 2e-3)
+    assert good.mean() > 0.6 and np.all(r1["converged"] == 1)
+    assert np.all(r1["fitness"][good] < 1e-3)
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    sel = list(range(0, 256, 32))
+    for b in sel:
+        ref = om.align(scans[int(off[b]):int(off[b + 1])], inits[b])
+        assert_result_parity(r1[b], ref)
+
+
+def test_multi_hypothesis_shared_scan(gpu, oracle, c1_world):
+    """configs[4] shape at small size: many seed poses x one scan."""
+    capi, ctx = gpu
+    from ndt_slam_amd import synth
+    m, sf, cfg = c1_world
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    scan, truth, _ = sf.make(0)
+    seeds = synth.hypothesis_seeds(truth, count=64, pitch=0.05, yaw_deg=2.0)
+    off = np.array([0, len(scan)], np.uint64)
+    res = gm.align_batch(scan, off, seeds, shared_scan=True)
+    for b in range(0, 64, 7):
+        assert_result_parity(res[b], om.align(scan, seeds[b]))
+    best = int(np.argmax(res["trans_prob"]))
+    ref_all = [om.align(scan, s)["trans_prob"] for s in seeds]
+    assert best == int(np.argmax(ref_all))
+
+
+def test_error_behaviour(gpu):
+    capi, ctx = gpu
+    with pytest.raises(capi.NdtError):
+        capi.Map(ctx, np.zeros((0, 2), np.float32), capi.default_params(resolution=0.5))
+    with pytest.raises(capi.NdtError):
+        capi.Map(ctx, np.full((10, 2), np.nan, np.float32), capi.default_params(resolution=0.5))
+    with pytest.raises(capi.NdtError):     # 2^28 voxel limit
+        capi.Map(ctx, np.array([[0, 0], [1e6, 1e6]], np.float32), capi.default_params(resolution=0.01))
+    gm = capi.Map(ctx, np.random.default_rng(0).uniform(0, 5, (500, 2)).astype(np.float32),
+                  capi.default_params(resolution=0.5))
+    with pytest.raises(capi.NdtError):
+        gm.align(np.zeros((0, 2), np.float32), [0, 0, 0])
+
+
+def test_pose_estimator_shim(gpu, oracle, c1_world):
+    """The PoseEstimator mirror keeps the reference's units and sentinel (src/PoseEstimator.cpp:4-69)."""
+    capi, ctx = gpu
+    from ndt_slam_amd.pose_estimator import PoseEstimator, Pose2D, Scan2D, approximate_voxel_grid, RAD2DEG
+    m, sf, cfg = c1_world
+    scan, truth, init = sf.make(3)
+    est = PoseEstimator(ctx, Resolution=0.3, LeafSize=0.05)           # ndt_mapping.launch:32-36
+    est.setScanPair(Scan2D(scan.astype(np.float64)), m)
+    cost, pose, cov = est.estimatePose(Pose2D(init[0], init[1], RAD2DEG(init[2])))
+    filtered = approximate_voxel_grid(scan, 0.05)
+    assert np.array_equal(filtered, oracle.approx_voxel_filter(scan, 0.05))
+    om = oracle.Map(m, oracle.default_params(resolution=0.3))
+    ref = om.align(filtered, [init[0], init[1], RAD2DEG(init[2]) * math.pi / 180])
+    assert cost == pytest.approx(ref["fitness"], rel=1e-12)
+    assert (pose.tx, pose.ty) == (ref["pose"][0], ref["pose"][1])
+    assert pose.th == pytest.approx(RAD2DEG(ref["pose"][2]), abs=1e-4 * 180 / math.pi)
+    assert cov == pytest.approx(np.linalg.inv(-ref["H"].reshape(3, 3)), rel=1e-6)
