@@ -70,8 +70,12 @@ def main():
     scans, off, truths, inits = sf.batch(rank * B, B)
 
     ctx = capi.Context(local_rank)
-    stream = torch.cuda.current_stream()
-    ctx.set_stream(stream.cuda_stream)      # map build and matches ordered on torch's stream
+    # a dedicated (non-null) torch stream: map build, matches, events and the gather are all
+    # ordered on it (the C ABI reads a NULL stream argument as "the context's own stream")
+    stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
+    ctx.set_stream(stream.cuda_stream)
     prm = capi.default_params(resolution=cfg["resolution"])     # otherwise ndt_mapping.launch:32-36
     d_map = torch.from_numpy(map_xy).to(dev)
     d_scans = torch.from_numpy(scans).to(dev)
@@ -177,7 +181,7 @@ def main():
         t = time.perf_counter()
         ref = om.align_batch(scans[:int(sub_off[-1])], sub_off, inits[:ns], nthreads=1)
         t_align = time.perf_counter() - t
-        ncpu = os.cpu_count() or 1
+        ncpu = min(16, os.cpu_count() or 1)     # the box's CPU share for one GPU
         t = time.perf_counter()
         om.align_batch(scans[:int(sub_off[-1])], sub_off, inits[:ns], nthreads=ncpu)
         t_all = time.perf_counter() - t

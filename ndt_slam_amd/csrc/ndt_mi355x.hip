@@ -62,7 +62,8 @@ struct Tf32 { float c, s, tx, ty; };
 
 // eleven partial sums of one derivative pass
 struct Acc {
-  double e, g0, g1, g2, hxx, hxy, hxt, hyy, hyt, htt, pairs;
+  double e, g0, g1, g2, hxx, hxy, hxt, hyy, hyt, htt;
+  unsigned pairs;
 };
 constexpr int kAcc = 11;
 
@@ -127,92 +128,195 @@ __device__ __forceinline__ void angle_cs(double snap, double yaw, double &c, dou
 // ------------------------------------------------------------------------------------------
 // a4 + a5: one source point -> its in-radius voxels -> score / gradient / Hessian terms
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void eval_point(const MapView &M, const Tf32 &T, float x, float y,
-                                           double cj, double sj, double ch, double sh, Acc &A) {
-  float xt, yt;
-  tf_apply(T, M.transform_sse, x, y, xt, yt);
-  if (!finite2(xt, yt)) return;
-  int ix = (int)floorf(xt * M.inv_leaf) - M.min_bx;
-  int iy = (int)floorf(yt * M.inv_leaf) - M.min_by;
-  if (ix < -1 || ix > M.div_x || iy < -1 || iy > M.div_y) return;
-  const int px = ix + 2, py = iy + 2;
-  const float2 *crow = M.cent + (size_t)(py - 1) * M.gw + (px - 1);
-  // radius search over voxel centroids (r = resolution): subset of the 3x3 neighbourhood.
-  unsigned mask = 0;
-#pragma unroll
-  for (int r = 0; r < 3; ++r) {
-#pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      float2 cc = crow[r * M.gw + q];
-      float ex = xt - cc.x, ey = yt - cc.y;
-      float dd = ex * ex + ey * ey;                      // flann::L2_Simple<float>
-      bool in = M.radius_inclusive ? (dd <= M.r2) : (dd < M.r2);
-      mask |= (in ? 1u : 0u) << (r * 3 + q);
-    }
-  }
-  if (!mask) return;
-  // yaw column of J_E and the (yaw,yaw) block of H_E (untransformed coordinates)
-  const double X = (double)x, Y = (double)y;
-  const double jx = X * (-sj) + Y * (-cj);
-  const double jy = X * cj + Y * (-sj);
-  const double hx = X * (-ch) + Y * sh;
-  const double hy = X * (-sh) + Y * (-ch);
-  const double XT = (double)xt, YT = (double)yt;
-  const double nd2 = -M.d2;
-  while (mask) {
-    int k = __builtin_ctz(mask);
-    mask &= mask - 1;
-    int r = k / 3, q = k - 3 * r;
-    const double *rec = M.rec + ((size_t)(py - 1 + r) * M.gw + (px - 1 + q)) * 8;
-    const double2 mu = *reinterpret_cast<const double2 *>(rec);
-    const double2 ia = *reinterpret_cast<const double2 *>(rec + 2);
-    const double i11 = rec[4];
-    const double i00 = ia.x, i01 = ia.y;
-    const double q0 = XT - mu.x, q1 = YT - mu.y;
-    const double u0 = __builtin_fma(i01, q1, i00 * q0);      // Sigma^-1 q
-    const double u1 = __builtin_fma(i11, q1, i01 * q0);
-    const double m = __builtin_fma(q1, u1, q0 * u0);
-    double e = exp(nd2 * m * 0.5);
-    const double e2 = M.d2 * e;
-    A.pairs += 1.0;
-    if (e2 > 1.0 || e2 < 0.0 || e2 != e2) e = 0.0;           // updateDerivatives error check
-    const double at = __builtin_fma(u1, jy, u0 * jx);        // q^T Sigma^-1 dT/dyaw
-    const double cx = __builtin_fma(i01, jy, i00 * jx);      // Sigma^-1 dT/dyaw
-    const double cy = __builtin_fma(i11, jy, i01 * jx);
-    const double v0 = nd2 * u0, v1 = nd2 * u1, vt = nd2 * at;
-    A.e += e;
-    A.g0 = __builtin_fma(e, u0, A.g0);
-    A.g1 = __builtin_fma(e, u1, A.g1);
-    A.g2 = __builtin_fma(e, at, A.g2);
-    A.hxx = __builtin_fma(e, __builtin_fma(v0, u0, i00), A.hxx);
-    A.hxy = __builtin_fma(e, __builtin_fma(v0, u1, i01), A.hxy);
-    A.hxt = __builtin_fma(e, __builtin_fma(v0, at, cx), A.hxt);
-    A.hyy = __builtin_fma(e, __builtin_fma(v1, u1, i11), A.hyy);
-    A.hyt = __builtin_fma(e, __builtin_fma(v1, at, cy), A.hyt);
-    double tt = __builtin_fma(jx, cx, jy * cy);              // J^T Sigma^-1 J
-    tt = __builtin_fma(u0, hx, tt);                          // + q^T Sigma^-1 d2T/dyaw2
-    tt = __builtin_fma(u1, hy, tt);
-    tt = __builtin_fma(vt, at, tt);
-    A.htt = __builtin_fma(e, tt, A.htt);
-  }
+
+// Per-scan window of the voxel grid staged in LDS (the cells a scan can reach while its pose
+// moves).  Two pieces share one LDS pool: a row-major rw x rh table of 16-bit slot numbers and a
+// compact table of the occupied voxels' records (48 B: float32 centroid, fp64 mean, fp64 inverse
+// covariance), so that the hot loop touches no global memory for map data.
+struct Region { int x0, y0, rw, rh, cap; };   // origin in unpadded voxel coordinates; cap = record slots
+struct __attribute__((aligned(16))) CellEntry { float2 cent; double mx, my, i00, i01, i11; };
+static_assert(sizeof(CellEntry) == 48, "CellEntry layout");
+constexpr int kRegionCells = 16384;           // at most 32 KiB of slot numbers
+constexpr int kRegionMargin = 5;              // cells of slack around the scan's first bbox
+constexpr int kPoolBytes = 156 * 1024;        // of the CU's 160 KiB LDS
+constexpr unsigned kSlotEmpty = 0xFFFFu;      // voxel not in the centroid search set
+constexpr unsigned kSlotSpill = 0xFFFEu;      // record did not fit the LDS pool: read it from HBM
+
+struct Window {
+  Region R;
+  const unsigned short *slot;                 // LDS
+  const CellEntry *ent;                       // LDS
+};
+
+// exp(x) for x <= ~0 (the NDT exponent -d2/2 * Mahalanobis^2): 2^(n/64) table * degree-5
+// polynomial, ~1 ulp.  x is clamped at -800 (underflows to 0), so a NaN exponent gives 0 --
+// the pair then adds nothing, exactly what the reference's `e != e` check does with it.
+__constant__ double c_exp2_tab[64];
+__device__ __forceinline__ double exp_neg(double x, const double *__restrict__ tab) {
+  x = fmax(x, -800.0);
+  const double t = rint(x * 92.332482616893657);            // 64 / ln 2
+  const int n = (int)t;
+  double r = __builtin_fma(-t, 0x1.62e42fefa0000p-7, x);    // ln2/64, high part (exact product)
+  r = __builtin_fma(-t, 0x1.cf79abc9e3b3ap-46, r);          // low part
+  double p = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);
+  p = __builtin_fma(r, p, 1.0 / 6.0);
+  p = __builtin_fma(r, p, 0.5);
+  p = __builtin_fma(p, r * r, r);                           // exp(r) - 1
+  const double sc = tab[n & 63];
+  return ldexp(__builtin_fma(sc, p, sc), n >> 6);
 }
 
-// Fixed-order sum over the workgroup.  Result valid in thread 0 only (and in sred[0..kAcc)).
+template <bool SSE>
+__device__ __forceinline__ void tf_apply_t(const Tf32 &t, float x, float y, float &ox, float &oy) {
+  const float ms = -t.s;
+  const float a = t.c * x, b = ms * y, c = t.s * x, d = t.c * y;
+  if (!SSE) { const float r = a + b; ox = r + t.tx; const float q = c + d; oy = q + t.ty; }
+  else      { const float r = b + t.tx; ox = a + r; const float q = d + t.ty; oy = c + q; }
+}
+
+// radius test of flann::L2_Simple<float> on one centroid
+template <bool INCL>
+__device__ __forceinline__ unsigned in_radius(float r2, float xt, float yt, float2 cc) {
+  const float ex = xt - cc.x, ey = yt - cc.y;
+  const float dd = ex * ex + ey * ey;
+  return (INCL ? (dd <= r2) : (dd < r2)) ? 1u : 0u;
+}
+
+struct CellRec { double mx, my, i00, i01, i11; };
+
+__device__ __forceinline__ CellRec load_rec_global(const MapView &M, size_t base, int k) {
+  const int r = (k * 11) >> 5, q = k - 3 * r;                 // k / 3 for k in [0, 9)
+  const double *rec = M.rec + (base + (size_t)(r * M.gw + q)) * 8;
+  const double2 a = *reinterpret_cast<const double2 *>(rec);
+  const double2 b = *reinterpret_cast<const double2 *>(rec + 2);
+  CellRec c; c.mx = a.x; c.my = a.y; c.i00 = b.x; c.i01 = b.y; c.i11 = rec[4];
+  return c;
+}
+
+struct PointTerms { double XT, YT, jx, jy, hx, hy; };
+
+__device__ __forceinline__ PointTerms point_terms(float x, float y, float xt, float yt, double cj,
+                                                  double sj, double ch, double sh) {
+  // yaw column of J_E and the (yaw,yaw) block of H_E (untransformed coordinates)
+  const double X = (double)x, Y = (double)y;
+  PointTerms P;
+  P.jx = X * (-sj) + Y * (-cj);
+  P.jy = X * cj + Y * (-sj);
+  P.hx = X * (-ch) + Y * sh;
+  P.hy = X * (-sh) + Y * (-ch);
+  P.XT = (double)xt; P.YT = (double)yt;
+  return P;
+}
+
+// one (point, voxel) pair: eqs 6.9 / 6.12 / 6.13 restricted to (tx, ty, yaw)
+__device__ __forceinline__ void accumulate_cell(double d2, const double *__restrict__ etab,
+                                                const PointTerms &P, const CellRec &c, Acc &A) {
+  const double nd2 = -d2;
+  const double q0 = P.XT - c.mx, q1 = P.YT - c.my;
+  const double u0 = __builtin_fma(c.i01, q1, c.i00 * q0);      // Sigma^-1 q
+  const double u1 = __builtin_fma(c.i11, q1, c.i01 * q0);
+  const double m = __builtin_fma(q1, u1, q0 * u0);
+  double e = exp_neg(nd2 * m * 0.5, etab);
+  const double e2 = d2 * e;
+  if (e2 > 1.0 || e2 < 0.0) e = 0.0;                           // updateDerivatives error check
+  const double at = __builtin_fma(u1, P.jy, u0 * P.jx);        // q^T Sigma^-1 dT/dyaw
+  const double cx = __builtin_fma(c.i01, P.jy, c.i00 * P.jx);  // Sigma^-1 dT/dyaw
+  const double cy = __builtin_fma(c.i11, P.jy, c.i01 * P.jx);
+  const double v0 = nd2 * u0, v1 = nd2 * u1, vt = nd2 * at;
+  A.e += e;
+  A.g0 = __builtin_fma(e, u0, A.g0);
+  A.g1 = __builtin_fma(e, u1, A.g1);
+  A.g2 = __builtin_fma(e, at, A.g2);
+  A.hxx = __builtin_fma(e, __builtin_fma(v0, u0, c.i00), A.hxx);
+  A.hxy = __builtin_fma(e, __builtin_fma(v0, u1, c.i01), A.hxy);
+  A.hxt = __builtin_fma(e, __builtin_fma(v0, at, cx), A.hxt);
+  A.hyy = __builtin_fma(e, __builtin_fma(v1, u1, c.i11), A.hyy);
+  A.hyt = __builtin_fma(e, __builtin_fma(v1, at, cy), A.hyt);
+  double tt = __builtin_fma(P.jx, cx, P.jy * cy);              // J^T Sigma^-1 J
+  tt = __builtin_fma(u0, P.hx, tt);                            // + q^T Sigma^-1 d2T/dyaw2
+  tt = __builtin_fma(u1, P.hy, tt);
+  tt = __builtin_fma(vt, at, tt);
+  A.htt = __builtin_fma(e, tt, A.htt);
+}
+
+// Everything one source point contributes to a derivative pass.
+// Fast path (point's 3x3 neighbourhood inside the LDS window, no spilled record among its
+// candidates): slot numbers, centroids and records all come from LDS.  Otherwise the same
+// arithmetic reads the global centroid grid / record array.
+template <bool SSE, bool INCL>
+__device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
+                                           const double *__restrict__ etab, const Tf32 &T, float x,
+                                           float y, double cj, double sj, double ch, double sh, Acc &A) {
+  float xt, yt;
+  tf_apply_t<SSE>(T, x, y, xt, yt);
+  const bool fin = finite2(xt, yt);
+  const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
+  const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
+  const int ix = (int)fx - M.min_bx, iy = (int)fy - M.min_by;
+  const bool ingrid = fin & (ix >= -1) & (ix <= M.div_x) & (iy >= -1) & (iy <= M.div_y);
+  const Region &R = W.R;
+  const int lx = ix - R.x0, ly = iy - R.y0;
+  const bool inwin = ingrid & (lx >= 1) & (lx < R.rw - 1) & (ly >= 1) & (ly < R.rh - 1);
+  // LDS probes with clamped indices (results dropped when !inwin)
+  const int clx = min(max(lx, 1), max(R.rw - 2, 1)), cly = min(max(ly, 1), max(R.rh - 2, 1));
+  const unsigned short *srow = W.slot + (cly - 1) * R.rw + (clx - 1);
+  unsigned mask = 0, spill = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const unsigned sl = srow[r * R.rw + q];
+      const bool member = sl < kSlotSpill;
+      spill |= (sl == kSlotSpill) ? 1u : 0u;
+      const float2 cc = W.ent[member ? sl : 0u].cent;
+      mask |= (member ? in_radius<INCL>(M.r2, xt, yt, cc) : 0u) << (r * 3 + q);
+    }
+  if (inwin & !spill) {
+    if (!mask) return;
+    A.pairs += __builtin_popcount(mask);
+    const PointTerms P = point_terms(x, y, xt, yt, cj, sj, ch, sh);
+#pragma nounroll
+    do {
+      const int k = __builtin_ctz(mask);
+      mask &= mask - 1;
+      const int r = (k * 11) >> 5, q = k - 3 * r;
+      const CellEntry &E = W.ent[srow[r * R.rw + q]];
+      CellRec c; c.mx = E.mx; c.my = E.my; c.i00 = E.i00; c.i01 = E.i01; c.i11 = E.i11;
+      accumulate_cell(M.d2, etab, P, c, A);
+    } while (mask);
+    return;
+  }
+  if (!ingrid) return;
+  // slow path: global centroid grid and record array
+  const size_t base = (size_t)(iy + 1) * M.gw + (ix + 1);     // padded coords of (ix-1, iy-1)
+  const float2 *grow = M.cent + base;
+  mask = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) mask |= in_radius<INCL>(M.r2, xt, yt, grow[r * M.gw + q]) << (r * 3 + q);
+  if (!mask) return;
+  A.pairs += __builtin_popcount(mask);
+  const PointTerms P = point_terms(x, y, xt, yt, cj, sj, ch, sh);
+#pragma nounroll
+  do {
+    const int k = __builtin_ctz(mask);
+    mask &= mask - 1;
+    accumulate_cell(M.d2, etab, P, load_rec_global(M, base, k), A);
+  } while (mask);
+}
+
+// Fixed-order sums over the workgroup: lanes by shuffle, waves through LDS in wave order.
+// Totals are left in sred[nw*NV .. nw*NV+NV) (valid for every thread after the call).
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
+  return x;
+}
+
 template <int NV>
-__device__ __forceinline__ void block_reduce(double (&v)[NV], double *sred /* [nwaves][NV] + [NV] */) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    double x = v[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o);
-    v[i] = x;
-  }
-  __syncthreads();   // sred may still be read by the previous round
-  if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < NV; ++i) sred[wave * NV + i] = v[i];
-  }
+__device__ __forceinline__ void block_combine(double *sred) {
+  const int nw = blockDim.x >> 6;
   __syncthreads();
   if (threadIdx.x < NV) {
     double s = 0.0;
@@ -220,52 +324,89 @@ __device__ __forceinline__ void block_reduce(double (&v)[NV], double *sred /* [n
     sred[nw * NV + threadIdx.x] = s;
   }
   __syncthreads();
-#pragma unroll
-  for (int i = 0; i < NV; ++i) v[i] = sred[nw * NV + i];
+}
+
+__device__ __forceinline__ void block_reduce_acc(const Acc &A, double *sred) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double *row = sred + wave * kAcc;
+  double t;
+  __syncthreads();   // sred may still be read from the previous round
+  t = wave_sum(A.e);     if (lane == 0) row[0] = t;
+  t = wave_sum(A.g0);    if (lane == 0) row[1] = t;
+  t = wave_sum(A.g1);    if (lane == 0) row[2] = t;
+  t = wave_sum(A.g2);    if (lane == 0) row[3] = t;
+  t = wave_sum(A.hxx);   if (lane == 0) row[4] = t;
+  t = wave_sum(A.hxy);   if (lane == 0) row[5] = t;
+  t = wave_sum(A.hxt);   if (lane == 0) row[6] = t;
+  t = wave_sum(A.hyy);   if (lane == 0) row[7] = t;
+  t = wave_sum(A.hyt);   if (lane == 0) row[8] = t;
+  t = wave_sum(A.htt);   if (lane == 0) row[9] = t;
+  t = wave_sum((double)A.pairs); if (lane == 0) row[10] = t;
+  block_combine<kAcc>(sred);
+}
+
+__device__ __forceinline__ void block_reduce2(double a, double b, double *sred) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double t;
+  __syncthreads();
+  t = wave_sum(a); if (lane == 0) sred[wave * 2 + 0] = t;
+  t = wave_sum(b); if (lane == 0) sred[wave * 2 + 1] = t;
+  block_combine<2>(sred);
 }
 
 // ------------------------------------------------------------------------------------------
 // a6: Newton step + More-Thuente line search as a resumable state machine
 // ------------------------------------------------------------------------------------------
 
-// Symmetric 3x3 pseudo-inverse solve (cyclic Jacobi); stands in for JacobiSVD<6x6>::solve on the
-// block-diagonal 6x6 (SURVEY.md 8a note).
-__device__ __noinline__ void solve3(const double Hs[6], const double b[3], double x[3]) {
-  double A[3][3] = {{Hs[0], Hs[1], Hs[2]}, {Hs[1], Hs[3], Hs[4]}, {Hs[2], Hs[4], Hs[5]}};
-  double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
-  for (int i = 0; i < 3; ++i)
-    for (int j = 0; j < 3; ++j)
-      if (A[i][j] != A[i][j]) { x[0] = x[1] = x[2] = NAN; return; }
-  for (int sweep = 0; sweep < 12; ++sweep) {
-    double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
-    if (off == 0.0) break;
-    for (int p = 0; p < 2; ++p)
-      for (int q = p + 1; q < 3; ++q) {
-        double apq = A[p][q];
-        if (apq == 0.0) continue;
-        double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-        double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        double app = A[p][p], aqq = A[q][q];
-        A[p][p] = app - t * apq; A[q][q] = aqq + t * apq; A[p][q] = A[q][p] = 0.0;
-        int r = 3 - p - q;
-        double arp = A[r][p], arq = A[r][q];
-        A[r][p] = A[p][r] = c * arp - s * arq;
-        A[r][q] = A[q][r] = s * arp + c * arq;
-        for (int k = 0; k < 3; ++k) {
-          double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
-        }
-      }
+// One Jacobi rotation annihilating a_pq of a symmetric 3x3 kept in scalars; r is the third index.
+__device__ __forceinline__ void jacobi_rot(double &app, double &aqq, double &apq, double &arp, double &arq,
+                                           double &v0p, double &v0q, double &v1p, double &v1q,
+                                           double &v2p, double &v2q) {
+  if (apq == 0.0) return;
+  const double theta = (aqq - app) / (2.0 * apq);
+  const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+  const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+  const double app0 = app, aqq0 = aqq;
+  app = app0 - t * apq; aqq = aqq0 + t * apq;
+  const double arp0 = arp, arq0 = arq;
+  arp = c * arp0 - s * arq0; arq = s * arp0 + c * arq0;
+  apq = 0.0;
+  double a, b;
+  a = v0p; b = v0q; v0p = c * a - s * b; v0q = s * a + c * b;
+  a = v1p; b = v1q; v1p = c * a - s * b; v1q = s * a + c * b;
+  a = v2p; b = v2q; v2p = c * a - s * b; v2q = s * a + c * b;
+}
+
+// Symmetric 3x3 pseudo-inverse solve (cyclic Jacobi, all state in registers); stands in for
+// JacobiSVD<6x6>::solve on the block-diagonal 6x6 (SURVEY.md 8a note).  Hs = xx xy xt yy yt tt.
+__device__ __forceinline__ void solve3(const double Hs[6], double b0, double b1, double b2,
+                                       double &x0, double &x1, double &x2) {
+  double a00 = Hs[0], a01 = Hs[1], a02 = Hs[2], a11 = Hs[3], a12 = Hs[4], a22 = Hs[5];
+  if (a00 != a00 || a01 != a01 || a02 != a02 || a11 != a11 || a12 != a12 || a22 != a22) {
+    x0 = x1 = x2 = NAN; return;
   }
-  double lmax = fmax(fabs(A[0][0]), fmax(fabs(A[1][1]), fabs(A[2][2])));
-  double thr = lmax * (6.0 * DBL_EPSILON);
-  x[0] = x[1] = x[2] = 0.0;
-  for (int k = 0; k < 3; ++k) {
-    double l = A[k][k];
-    if (!(fabs(l) > thr) || fabs(l) < DBL_MIN) continue;
-    double proj = (V[0][k] * b[0] + V[1][k] * b[1] + V[2][k] * b[2]) / l;
-    x[0] += V[0][k] * proj; x[1] += V[1][k] * proj; x[2] += V[2][k] * proj;
+  double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = fabs(a01) + fabs(a02) + fabs(a12);
+    if (off == 0.0) break;
+    jacobi_rot(a00, a11, a01, a02, a12, v00, v01, v10, v11, v20, v21);   // (p,q) = (0,1), r = 2
+    jacobi_rot(a00, a22, a02, a01, a12, v00, v02, v10, v12, v20, v22);   // (0,2), r = 1
+    jacobi_rot(a11, a22, a12, a01, a02, v01, v02, v11, v12, v21, v22);   // (1,2), r = 0
+  }
+  const double lmax = fmax(fabs(a00), fmax(fabs(a11), fabs(a22)));
+  const double thr = lmax * (6.0 * DBL_EPSILON);
+  x0 = x1 = x2 = 0.0;
+  if (fabs(a00) > thr && !(fabs(a00) < DBL_MIN)) {
+    const double pr = (v00 * b0 + v10 * b1 + v20 * b2) / a00;
+    x0 += v00 * pr; x1 += v10 * pr; x2 += v20 * pr;
+  }
+  if (fabs(a11) > thr && !(fabs(a11) < DBL_MIN)) {
+    const double pr = (v01 * b0 + v11 * b1 + v21 * b2) / a11;
+    x0 += v01 * pr; x1 += v11 * pr; x2 += v21 * pr;
+  }
+  if (fabs(a22) > thr && !(fabs(a22) < DBL_MIN)) {
+    const double pr = (v02 * b0 + v12 * b1 + v22 * b2) / a22;
+    x0 += v02 * pr; x1 += v12 * pr; x2 += v22 * pr;
   }
 }
 
@@ -324,11 +465,11 @@ __device__ __forceinline__ void set_trial(AlignState &S, const OptParams &P, boo
 // Start (or finish) outer iterations until a derivative pass is needed or the match is done.
 __device__ __noinline__ void begin_outer(AlignState &S, const OptParams &P) {
   for (;;) {
-    double mg[3] = {-S.g[0], -S.g[1], -S.g[2]}, dp[3];
-    solve3(S.H, mg, dp);
-    double nrm = sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]);
+    double dp0, dp1, dp2;
+    solve3(S.H, -S.g[0], -S.g[1], -S.g[2], dp0, dp1, dp2);
+    double nrm = sqrt(dp0 * dp0 + dp1 * dp1 + dp2 * dp2);
     if (nrm == 0 || nrm != nrm) { S.converged = (nrm == nrm); S.phase = PH_DONE; return; }
-    S.dir[0] = dp[0] / nrm; S.dir[1] = dp[1] / nrm; S.dir[2] = dp[2] / nrm;
+    S.dir[0] = dp0 / nrm; S.dir[1] = dp1 / nrm; S.dir[2] = dp2 / nrm;
     S.phi0 = -S.score;
     S.dphi0 = -(S.g[0] * S.dir[0] + S.g[1] * S.dir[1] + S.g[2] * S.dir[2]);
     double a = 0.0;
@@ -451,46 +592,77 @@ __device__ __forceinline__ double yaw_from_T(float T00, float T10) {
 }
 
 // ------------------------------------------------------------------------------------------
-// a7: nearest raw map point by ring search over the voxel buckets (exact, no range cut)
+// a7: nearest raw map point, exact, no range cut: home voxel, then the ring-1 voxels that can
+// still hold a closer point (box-distance pruning), then whole rings while the best distance
+// exceeds the ring bound.
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float scan_bucket(const float2 *__restrict__ pts, int s, int se, float qx,
+                                             float qy, float best) {
+  for (; s + 4 <= se; s += 4) {              // four independent loads in flight
+    const float2 p0 = pts[s], p1 = pts[s + 1], p2 = pts[s + 2], p3 = pts[s + 3];
+    float ex, ey, d0, d1, d2, d3;
+    ex = qx - p0.x; ey = qy - p0.y; d0 = ex * ex + ey * ey;
+    ex = qx - p1.x; ey = qy - p1.y; d1 = ex * ex + ey * ey;
+    ex = qx - p2.x; ey = qy - p2.y; d2 = ex * ex + ey * ey;
+    ex = qx - p3.x; ey = qy - p3.y; d3 = ex * ex + ey * ey;
+    best = fminf(best, fminf(fminf(d0, d1), fminf(d2, d3)));
+  }
+  for (; s < se; ++s) {
+    const float2 p = pts[s];
+    const float ex = qx - p.x, ey = qy - p.y;
+    best = fminf(best, ex * ex + ey * ey);
+  }
+  return best;
+}
+
 __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy) {
-  int cx = (int)floorf(qx * M.inv_leaf) - M.min_bx, cy = (int)floorf(qy * M.inv_leaf) - M.min_by;
-  cx = cx < 0 ? 0 : (cx >= M.div_x ? M.div_x - 1 : cx);
-  cy = cy < 0 ? 0 : (cy >= M.div_y ? M.div_y - 1 : cy);
-  float best = INFINITY;
+  const int cx0 = (int)floorf(qx * M.inv_leaf) - M.min_bx, cy0 = (int)floorf(qy * M.inv_leaf) - M.min_by;
+  const int cx = cx0 < 0 ? 0 : (cx0 >= M.div_x ? M.div_x - 1 : cx0);
+  const int cy = cy0 < 0 ? 0 : (cy0 >= M.div_y ? M.div_y - 1 : cy0);
+  const bool inside = (cx == cx0) && (cy == cy0);
+  const int *__restrict__ ps = M.pt_start;
+  const size_t gh = (size_t)cy * M.div_x + cx;
+  float best = scan_bucket(M.pts, ps[gh], ps[gh + 1], qx, qy, INFINITY);
+  // distances from the query to the four walls of its voxel, shrunk by 1e-3 leaf so that a point
+  // the float32 voxel rounding put on the other side of a wall is never pruned away
+  const float L = M.leaf, slack = 1e-3f * L;
+  const float fx = qx - (float)(cx + M.min_bx) * L, fy = qy - (float)(cy + M.min_by) * L;
+  float wl = fmaxf(fx - slack, 0.f), wr = fmaxf(L - fx - slack, 0.f);
+  float wd = fmaxf(fy - slack, 0.f), wu = fmaxf(L - fy - slack, 0.f);
+  if (!inside) { wl = wr = wd = wu = 0.f; }            // clamped query: no pruning
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = cy + dy;
+    if (yy < 0 || yy >= M.div_y) continue;
+    const float by = dy < 0 ? wd : (dy > 0 ? wu : 0.f);
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      if (dx == 0 && dy == 0) continue;
+      const int xx = cx + dx;
+      if (xx < 0 || xx >= M.div_x) continue;
+      const float bx = dx < 0 ? wl : (dx > 0 ? wr : 0.f);
+      if (!(bx * bx + by * by < best)) continue;       // that voxel cannot hold a closer point
+      const size_t g = (size_t)yy * M.div_x + xx;
+      best = scan_bucket(M.pts, ps[g], ps[g + 1], qx, qy, best);
+    }
+  }
+  const double Ld = (double)L;
   const int rmax = M.div_x > M.div_y ? M.div_x : M.div_y;
-  const double L = (double)M.leaf;
-  for (int r = 0; r <= rmax; ++r) {
-    const int y0 = cy - r, y1 = cy + r, x0 = cx - r, x1 = cx + r;
+  for (int r = 1; r <= rmax; ++r) {
+    const double bound = (double)r * Ld * 0.999;        // unvisited points are farther than r*L
+    if ((double)best <= bound * bound) break;
+    const int R = r + 1;                                // visit the whole ring R
+    const int y0 = cy - R, y1 = cy + R, x0 = cx - R, x1 = cx + R;
     for (int yy = (y0 < 0 ? 0 : y0); yy <= y1 && yy < M.div_y; ++yy) {
-      const bool edge = (yy == y0 || yy == y1);
-      if (edge) {
-        // whole row segment [x0, x1]: buckets of consecutive voxels are contiguous
-        int xa = x0 < 0 ? 0 : x0, xb = x1 >= M.div_x ? M.div_x - 1 : x1;
-        if (xa > xb) continue;
-        size_t g = (size_t)yy * M.div_x;
-        for (int s = M.pt_start[g + xa], se = M.pt_start[g + xb + 1]; s < se; ++s) {
-          float2 p = M.pts[s];
-          float ex = qx - p.x, ey = qy - p.y;
-          float dd = ex * ex + ey * ey;
-          best = dd < best ? dd : best;
-        }
+      const size_t g = (size_t)yy * M.div_x;
+      if (yy == y0 || yy == y1) {
+        const int xa = x0 < 0 ? 0 : x0, xb = x1 >= M.div_x ? M.div_x - 1 : x1;
+        if (xa <= xb) best = scan_bucket(M.pts, ps[g + xa], ps[g + xb + 1], qx, qy, best);
       } else {
-        for (int side = 0; side < 2; ++side) {
-          int xx = side ? x1 : x0;
-          if (xx < 0 || xx >= M.div_x || (side && x1 == x0)) continue;
-          size_t g = (size_t)yy * M.div_x + xx;
-          for (int s = M.pt_start[g], se = M.pt_start[g + 1]; s < se; ++s) {
-            float2 p = M.pts[s];
-            float ex = qx - p.x, ey = qy - p.y;
-            float dd = ex * ex + ey * ey;
-            best = dd < best ? dd : best;
-          }
-        }
+        if (x0 >= 0 && x0 < M.div_x) best = scan_bucket(M.pts, ps[g + x0], ps[g + x0 + 1], qx, qy, best);
+        if (x1 >= 0 && x1 < M.div_x) best = scan_bucket(M.pts, ps[g + x1], ps[g + x1 + 1], qx, qy, best);
       }
     }
-    double bound = (double)r * L * 0.999;    // unvisited points are farther than r*L
-    if ((double)best <= bound * bound) break;
   }
   return best;
 }
@@ -498,16 +670,35 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
 // ------------------------------------------------------------------------------------------
 // the match kernel: one workgroup per scan, the whole optimisation on the device
 // ------------------------------------------------------------------------------------------
-constexpr int kBlock = 1024;
+constexpr int kBlock = 512;
 constexpr int kWaves = kBlock / 64;
 
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_down(v, o); v = t < v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_down(v, o); v = t > v ? t : v; }
+  return v;
+}
+
+template <bool SSE, bool INCL>
 __global__ void __launch_bounds__(kBlock)
 ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
                  const unsigned long long *__restrict__ offsets, int B, int shared_scan,
                  const double *__restrict__ inits, ndt_result *__restrict__ results,
-                 double *__restrict__ trace, int trace_cap, int *__restrict__ trace_rows) {
+                 double *__restrict__ trace, int trace_cap, int *__restrict__ trace_rows,
+                 unsigned long long *__restrict__ prof /* diagnostic: 4 x ticks per scan */) {
   __shared__ AlignState S;
   __shared__ double sred[(kWaves + 1) * kAcc];
+  __shared__ Region RG;
+  __shared__ int sbox[4];
+  __shared__ int swave[kWaves + 1];
+  __shared__ double etab[64];
+  __shared__ uint4 pool[kPoolBytes / 16];
+  if (threadIdx.x < 64) etab[threadIdx.x] = c_exp2_tab[threadIdx.x];
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
     const unsigned long long o1 = shared_scan ? offsets[1] : offsets[b + 1];
@@ -519,92 +710,219 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       init_state(S, P, inits + 3 * (size_t)b, (double)n);
       if (trace_rows) trace_rows[b] = 0;
       if (n <= 0) { S.phase = PH_DONE; S.converged = 0; }
+      sbox[0] = INT_MAX; sbox[1] = INT_MAX; sbox[2] = INT_MIN; sbox[3] = INT_MIN;
     }
     __syncthreads();
+    // ---- stage the part of the map this scan can reach in LDS ----
+    {
+      const Tf32 T0 = S.T;
+      int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+      for (int i = threadIdx.x; i < n; i += kBlock) {
+        const float2 pt = scan[i];
+        float xt, yt;
+        tf_apply_t<SSE>(T0, pt.x, pt.y, xt, yt);
+        if (!finite2(xt, yt)) continue;
+        const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
+        const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
+        const int ix = (int)fx - M.min_bx, iy = (int)fy - M.min_by;
+        mnx = ix < mnx ? ix : mnx; mxx = ix > mxx ? ix : mxx;
+        mny = iy < mny ? iy : mny; mxy = iy > mxy ? iy : mxy;
+      }
+      mnx = wave_min_i(mnx); mny = wave_min_i(mny); mxx = wave_max_i(mxx); mxy = wave_max_i(mxy);
+      if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
+        atomicMin(&sbox[0], mnx); atomicMin(&sbox[1], mny); atomicMax(&sbox[2], mxx); atomicMax(&sbox[3], mxy);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        Region r = {0, 0, 0, 0, 0};
+        if (sbox[0] <= sbox[2]) {
+          // clip the bbox to the padded map grid, add the slack, then fit the slot-table budget
+          // around the bbox centre
+          long long x0 = (long long)sbox[0] - kRegionMargin, x1 = (long long)sbox[2] + kRegionMargin;
+          long long y0 = (long long)sbox[1] - kRegionMargin, y1 = (long long)sbox[3] + kRegionMargin;
+          x0 = x0 < -2 ? -2 : x0; y0 = y0 < -2 ? -2 : y0;
+          x1 = x1 > M.div_x + 1 ? M.div_x + 1 : x1; y1 = y1 > M.div_y + 1 ? M.div_y + 1 : y1;
+          long long w = x1 - x0 + 1, h = y1 - y0 + 1;
+          if (w > 0 && h > 0) {
+            if (w * h > kRegionCells) {
+              long long w2 = w > 128 ? 128 : w;
+              long long h2 = kRegionCells / w2; if (h2 > h) h2 = h;
+              x0 += (w - w2) / 2; y0 += (h - h2) / 2; w = w2; h = h2;
+            }
+            r.x0 = (int)x0; r.y0 = (int)y0; r.rw = (int)w; r.rh = (int)h;
+          }
+        }
+        const int slot_bytes = ((r.rw * r.rh * 2 + 15) / 16) * 16;
+        int cap = (kPoolBytes - slot_bytes) / (int)sizeof(CellEntry) - 1;
+        r.cap = cap > (int)kSlotSpill - 1 ? (int)kSlotSpill - 1 : cap;
+        RG = r;
+      }
+      __syncthreads();
+      const Region r = RG;
+      unsigned short *slot = reinterpret_cast<unsigned short *>(pool);
+      CellEntry *ent = reinterpret_cast<CellEntry *>(reinterpret_cast<char *>(pool) +
+                                                     ((r.rw * r.rh * 2 + 15) / 16) * 16);
+      // each lane owns a contiguous run of window cells: slots are numbered in row-major order,
+      // so which records spill (if any) does not depend on timing
+      const int ncell = r.rw * r.rh;
+      const int per = (ncell + kBlock - 1) / kBlock;
+      const int c0 = threadIdx.x * per, c1 = min(c0 + per, ncell);
+      int mine = 0;
+      for (int c = c0; c < c1; ++c) {
+        const int ly = c / r.rw, lx = c - ly * r.rw;
+        const float2 cc = M.cent[(size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2)];
+        mine += (cc.x < INFINITY) ? 1 : 0;      // +inf marks voxels outside the search set
+      }
+      // exclusive prefix of `mine` over the workgroup
+      int incl = mine;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)(threadIdx.x & 63) >= o) incl += t; }
+      if ((threadIdx.x & 63) == 63) swave[threadIdx.x >> 6] = incl;
+      __syncthreads();
+      if (threadIdx.x == 0) { int run = 0; for (int w = 0; w < kWaves; ++w) { const int t = swave[w]; swave[w] = run; run += t; } swave[kWaves] = run; }
+      __syncthreads();
+      int next = swave[threadIdx.x >> 6] + incl - mine;
+      if (threadIdx.x == 0) {
+        CellEntry z; z.cent = make_float2(INFINITY, INFINITY); z.mx = z.my = z.i00 = z.i01 = z.i11 = 0.0;
+        ent[r.cap] = z;                          // never indexed by a slot; keeps slot 0 reads defined when empty
+        if (swave[kWaves] == 0) ent[0] = z;
+      }
+      for (int c = c0; c < c1; ++c) {
+        const int ly = c / r.rw, lx = c - ly * r.rw;
+        const size_t pg = (size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2);
+        const float2 cc = M.cent[pg];
+        unsigned sl = kSlotEmpty;
+        if (cc.x < INFINITY) {
+          if (next < r.cap) {
+            const double *rec = M.rec + pg * 8;
+            CellEntry E; E.cent = cc; E.mx = rec[0]; E.my = rec[1]; E.i00 = rec[2]; E.i01 = rec[3]; E.i11 = rec[4];
+            ent[next] = E;
+            sl = (unsigned)next;
+          } else {
+            sl = kSlotSpill;
+          }
+          ++next;
+        }
+        slot[c] = (unsigned short)sl;
+      }
+      __syncthreads();
+    }
+    Window W;
+    W.R = RG;
+    W.slot = reinterpret_cast<const unsigned short *>(pool);
+    W.ent = reinterpret_cast<const CellEntry *>(reinterpret_cast<const char *>(pool) +
+                                                ((W.R.rw * W.R.rh * 2 + 15) / 16) * 16);
+    unsigned long long t_eval = 0, t_adv = 0, t0 = 0, t1 = 0;
     // ---- optimisation loop: every iteration is one derivative pass (HOT LOOP A+B fused) ----
     for (;;) {
       if (S.phase == PH_DONE) break;
+      if (prof) t0 = wall_clock64();
       const Tf32 T = S.T;
       const double cj = S.cj, sj = S.sj, ch = S.ch, sh = S.sh;
-      Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-      for (int i = threadIdx.x; i < n; i += kBlock) {
-        float2 pt = scan[i];
-        eval_point(M, T, pt.x, pt.y, cj, sj, ch, sh, A);
+      Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+      // the lane's points come from L2 (coalesced, two loads kept in flight); all map data from LDS
+      {
+        const int last = n - 1;
+        int i = threadIdx.x;
+        float2 p0 = scan[min(i, last)], p1 = scan[min(i + kBlock, last)];
+#pragma nounroll
+        for (; i < n; i += kBlock) {
+          const float2 p2 = scan[min(i + 2 * kBlock, last)];
+          eval_point<SSE, INCL>(M, W, etab, T, p0.x, p0.y, cj, sj, ch, sh, A);
+          p0 = p1; p1 = p2;
+        }
       }
-      double v[kAcc] = {A.e, A.g0, A.g1, A.g2, A.hxx, A.hxy, A.hxt, A.hyy, A.hyt, A.htt, A.pairs};
-      block_reduce<kAcc>(v, sred);
-      if (threadIdx.x == 0) advance(S, P, M, v, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
+      block_reduce_acc(A, sred);
+      if (prof) { t1 = wall_clock64(); t_eval += t1 - t0; }
+      if (threadIdx.x == 0)
+        advance(S, P, M, sred + kWaves * kAcc, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
       __syncthreads();
+      if (prof) t_adv += wall_clock64() - t1;
     }
     // ---- epilogue: fitness score at the final float32 transform (HOT LOOP C) ----
+    if (prof) t0 = wall_clock64();
     const Tf32 T = S.T;
-    double fs[2] = {0.0, 0.0};
-    for (int i = threadIdx.x; i < n; i += kBlock) {
-      float2 pt = scan[i];
+    double fsum = 0.0, fcnt = 0.0;
+    auto fit = [&](float x, float y) {
       float qx, qy;
-      tf_apply(T, M.transform_sse, pt.x, pt.y, qx, qy);
-      if (!finite2(qx, qy)) continue;
+      tf_apply_t<SSE>(T, x, y, qx, qy);
+      if (!finite2(qx, qy)) return;
       float best = nearest_sq(M, qx, qy);
-      if (best < INFINITY) { fs[0] += (double)best; fs[1] += 1.0; }
-    }
-    block_reduce<2>(fs, sred);
+      if (best < INFINITY) { fsum += (double)best; fcnt += 1.0; }
+    };
+    for (int i = threadIdx.x; i < n; i += kBlock) { float2 pt = scan[i]; fit(pt.x, pt.y); }
+    block_reduce2(fsum, fcnt, sred);
     if (threadIdx.x == 0) {
-      ndt_result R;
-      R.pose[0] = (double)T.tx; R.pose[1] = (double)T.ty; R.pose[2] = yaw_from_T(T.c, T.s);
-      R.T00 = T.c; R.T10 = T.s; R.T03 = T.tx; R.T13 = T.ty;
-      R.fitness = fs[1] > 0 ? fs[0] / fs[1] : DBL_MAX;
-      R.score = S.score;
-      R.trans_prob = n > 0 ? S.score / (double)n : 0.0;
-      R.H[0] = S.H[0]; R.H[1] = S.H[1]; R.H[2] = S.H[2];
-      R.H[3] = S.H[1]; R.H[4] = S.H[3]; R.H[5] = S.H[4];
-      R.H[6] = S.H[2]; R.H[7] = S.H[4]; R.H[8] = S.H[5];
-      R.p[0] = S.p[0]; R.p[1] = S.p[1]; R.p[2] = S.p[2];
-      R.iters = S.iters; R.evals = S.evals;
-      R.ref_evals = S.ref_evals + 1;       // + the getHessian pass (src/PoseEstimator.cpp:56)
-      R.converged = S.converged;
-      R.status = n > 0 ? NDT_OK : NDT_E_ARG;
-      R.pad_ = 0;
-      R.kbar = (S.evals > 0 && n > 0) ? S.pairs / ((double)S.evals * (double)n) : 0.0;
-      results[b] = R;
+      const double fs[2] = {sred[kWaves * 2], sred[kWaves * 2 + 1]};
+      ndt_result R_;
+      R_.pose[0] = (double)T.tx; R_.pose[1] = (double)T.ty; R_.pose[2] = yaw_from_T(T.c, T.s);
+      R_.T00 = T.c; R_.T10 = T.s; R_.T03 = T.tx; R_.T13 = T.ty;
+      R_.fitness = fs[1] > 0 ? fs[0] / fs[1] : DBL_MAX;
+      R_.score = S.score;
+      R_.trans_prob = n > 0 ? S.score / (double)n : 0.0;
+      R_.H[0] = S.H[0]; R_.H[1] = S.H[1]; R_.H[2] = S.H[2];
+      R_.H[3] = S.H[1]; R_.H[4] = S.H[3]; R_.H[5] = S.H[4];
+      R_.H[6] = S.H[2]; R_.H[7] = S.H[4]; R_.H[8] = S.H[5];
+      R_.p[0] = S.p[0]; R_.p[1] = S.p[1]; R_.p[2] = S.p[2];
+      R_.iters = S.iters; R_.evals = S.evals;
+      R_.ref_evals = S.ref_evals + 1;       // + the getHessian pass (src/PoseEstimator.cpp:56)
+      R_.converged = S.converged;
+      R_.status = n > 0 ? NDT_OK : NDT_E_ARG;
+      R_.pad_ = 0;
+      R_.kbar = (S.evals > 0 && n > 0) ? S.pairs / ((double)S.evals * (double)n) : 0.0;
+      results[b] = R_;
+      if (prof) {
+        prof[4 * b + 0] = t_eval; prof[4 * b + 1] = t_adv; prof[4 * b + 2] = wall_clock64() - t0;
+        prof[4 * b + 3] = (unsigned long long)S.evals;
+      }
     }
   }
 }
 
 // One derivative pass at an explicit pose (tests / profiling): grid-stride over points,
 // one partial record per workgroup, summed on the host in block order.
+template <bool SSE, bool INCL>
 __global__ void __launch_bounds__(256)
 ndt_eval_kernel(MapView M, double snap, const float *__restrict__ scan, size_t stride, int n,
                 double p0, double p1, double p2, double *__restrict__ partial /* grid x kAcc */) {
   __shared__ double sred[(4 + 1) * kAcc];
+  __shared__ double etab[64];
+  __shared__ unsigned short no_slot[16];
+  __shared__ CellEntry no_ent[1];
+  if (threadIdx.x < 64) etab[threadIdx.x] = c_exp2_tab[threadIdx.x];
+  if (threadIdx.x < 16) no_slot[threadIdx.x] = (unsigned short)kSlotEmpty;
+  if (threadIdx.x == 0) { no_ent[0].cent = make_float2(INFINITY, INFINITY); no_ent[0].mx = no_ent[0].my = 0; no_ent[0].i00 = no_ent[0].i01 = no_ent[0].i11 = 0; }
+  __syncthreads();
   double p[3] = {p0, p1, p2};
   Tf32 T = tf_from_p(p);
   double cj, sj;
   angle_cs(snap, p2, cj, sj);
-  Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+  Window W;
+  W.R = Region{0, 0, 0, 0, 0}; W.slot = no_slot; W.ent = no_ent;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float2 pt = load_pt(scan, stride, i);
-    eval_point(M, T, pt.x, pt.y, cj, sj, cj, sj, A);
+    eval_point<SSE, INCL>(M, W, etab, T, pt.x, pt.y, cj, sj, cj, sj, A);
   }
-  double v[kAcc] = {A.e, A.g0, A.g1, A.g2, A.hxx, A.hxy, A.hxt, A.hyy, A.hyt, A.htt, A.pairs};
-  block_reduce<kAcc>(v, sred);
-  if (threadIdx.x < kAcc) partial[blockIdx.x * kAcc + threadIdx.x] = v[threadIdx.x];
+  block_reduce_acc(A, sred);
+  if (threadIdx.x < kAcc) partial[blockIdx.x * kAcc + threadIdx.x] = sred[4 * kAcc + threadIdx.x];
 }
 
 __global__ void __launch_bounds__(256)
 ndt_fitness_kernel(MapView M, const float *__restrict__ scan, size_t stride, int n, Tf32 T,
                    double *__restrict__ partial /* grid x 2 */) {
   __shared__ double sred[(4 + 1) * 2];
-  double fs[2] = {0.0, 0.0};
+  double fsum = 0.0, fcnt = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float2 pt = load_pt(scan, stride, i);
     float qx, qy;
     tf_apply(T, M.transform_sse, pt.x, pt.y, qx, qy);
     if (!finite2(qx, qy)) continue;
     float best = nearest_sq(M, qx, qy);
-    if (best < INFINITY) { fs[0] += (double)best; fs[1] += 1.0; }
+    if (best < INFINITY) { fsum += (double)best; fcnt += 1.0; }
   }
-  block_reduce<2>(fs, sred);
-  if (threadIdx.x < 2) partial[blockIdx.x * 2 + threadIdx.x] = fs[threadIdx.x];
+  block_reduce2(fsum, fcnt, sred);
+  if (threadIdx.x < 2) partial[blockIdx.x * 2 + threadIdx.x] = sred[4 * 2 + threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -628,8 +946,9 @@ __host__ __device__ inline float ord2f(unsigned u) {
 }
 
 // getMinMax3D: bounds[0..3] = ord(min x), ord(min y), ord(max x), ord(max y)
-__global__ void map_minmax_kernel(const float *__restrict__ xy, size_t stride, size_t n,
-                                  unsigned *__restrict__ bounds) {
+__global__ void __launch_bounds__(256)
+map_minmax_kernel(const float *__restrict__ xy, size_t stride, size_t n, unsigned *__restrict__ bounds) {
+  __shared__ float sh[4][4];
   float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float2 p = load_pt(xy, stride, i);
@@ -642,9 +961,18 @@ __global__ void map_minmax_kernel(const float *__restrict__ xy, size_t stride, s
     mnx = fminf(mnx, __shfl_down(mnx, o)); mny = fminf(mny, __shfl_down(mny, o));
     mxx = fmaxf(mxx, __shfl_down(mxx, o)); mxy = fmaxf(mxy, __shfl_down(mxy, o));
   }
-  if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
-    atomicMin(&bounds[0], f2ord(mnx)); atomicMin(&bounds[1], f2ord(mny));
-    atomicMax(&bounds[2], f2ord(mxx)); atomicMax(&bounds[3], f2ord(mxy));
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w][0] = mnx; sh[w][1] = mny; sh[w][2] = mxx; sh[w][3] = mxy; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) {
+      mnx = fminf(mnx, sh[k][0]); mny = fminf(mny, sh[k][1]);
+      mxx = fmaxf(mxx, sh[k][2]); mxy = fmaxf(mxy, sh[k][3]);
+    }
+    if (mnx <= mxx) {     // one atomic set per workgroup
+      atomicMin(&bounds[0], f2ord(mnx)); atomicMin(&bounds[1], f2ord(mny));
+      atomicMax(&bounds[2], f2ord(mxx)); atomicMax(&bounds[3], f2ord(mxy));
+    }
   }
 }
 
@@ -957,11 +1285,37 @@ void gauss_constants(const ndt_params &p, double *d1, double *d2) {
   *d2 = -2.0 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / *d1);
 }
 
+// exp table 2^(j/64), correctly rounded, uploaded once per device
+int upload_exp_table(ndt_ctx *ctx);
+
 int grid_for(size_t n, int block, int cap = 2048) {
   size_t g = (n + block - 1) / block;
   if (g < 1) g = 1;
   if (g > (size_t)cap) g = cap;
   return (int)g;
+}
+
+void launch_align(const ndt_map *map, hipStream_t st, const float *scans, const unsigned long long *offsets,
+                  int B, int shared_scan, const double *inits, ndt_result *out, double *trace, int trace_cap,
+                  int *trace_rows, unsigned long long *prof) {
+  const bool sse = map->prm.transform_sse != 0, incl = map->prm.radius_inclusive != 0;
+  const MapView &V = map->view;
+  const OptParams O = opt_of(map->prm);
+#define NDT_LAUNCH(S_, I_)                                                                           \
+  ndt_align_kernel<S_, I_><<<B, kBlock, 0, st>>>(V, O, scans, offsets, B, shared_scan, inits, out, trace, \
+                                                 trace_cap, trace_rows, prof)
+  if (sse && incl) NDT_LAUNCH(true, true);
+  else if (sse)    NDT_LAUNCH(true, false);
+  else if (incl)   NDT_LAUNCH(false, true);
+  else             NDT_LAUNCH(false, false);
+#undef NDT_LAUNCH
+}
+
+int upload_exp_table(ndt_ctx *ctx) {
+  double tab[64];
+  for (int j = 0; j < 64; ++j) tab[j] = (double)exp2l((long double)j / 64.0L);
+  HIP_TRY(ctx, hipMemcpyToSymbol(HIP_SYMBOL(c_exp2_tab), tab, sizeof(tab)));
+  return NDT_OK;
 }
 
 }  // namespace
@@ -996,6 +1350,7 @@ int ndt_ctx_create(int device, ndt_ctx **out) {
   c->stream = c->own_stream;
   HIP_TRY(c, hipEventCreate(&c->ev0));
   HIP_TRY(c, hipEventCreate(&c->ev1));
+  { int rc = upload_exp_table(c); if (rc) return rc; }
   *out = c;
   return NDT_OK;
 }
@@ -1068,7 +1423,7 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
   // 1. bounding box (getMinMax3D)
   unsigned init_b[4] = {0xffffffffu, 0xffffffffu, 0u, 0u};
   HIP_TRY(ctx, hipMemcpyAsync(m->bounds, init_b, sizeof(init_b), hipMemcpyHostToDevice, st));
-  map_minmax_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, m->bounds);
+  map_minmax_kernel<<<grid_for(n, 256 * 16, 512), 256, 0, st>>>(xy, stride, n, m->bounds);
   unsigned hb[4];
   HIP_TRY(ctx, hipMemcpyAsync(hb, m->bounds, sizeof(hb), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
@@ -1211,9 +1566,8 @@ int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, co
   if (!map || !scans || !offsets || !inits || !out || B <= 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: bad arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-  ndt_align_kernel<<<B, kBlock, 0, st>>>(map->view, opt_of(map->prm), scans,
-                                         (const unsigned long long *)offsets, B, shared_scan, inits, out,
-                                         nullptr, 0, nullptr);
+  launch_align(map, st, scans, (const unsigned long long *)offsets, B, shared_scan, inits, out, nullptr, 0,
+               nullptr, nullptr);
   HIP_TRY(ctx, hipGetLastError());
   return NDT_OK;
 }
@@ -1245,13 +1599,29 @@ int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, 
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scan, scans, (size_t)offsets[nscan] * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off, offsets, (nscan + 1) * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_init, inits, (size_t)B * 24, hipMemcpyHostToDevice, st));
+  // diagnostic phase timing (NDT_PROF=1): not part of the ABI, prints to stderr
+  unsigned long long *d_prof = nullptr;
+  const bool want_prof = getenv("NDT_PROF") != nullptr;
+  if (want_prof) HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 32));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
-  ndt_align_kernel<<<B, kBlock, 0, st>>>(map->view, opt_of(map->prm), (const float *)ctx->d_scan,
-                                         (const unsigned long long *)ctx->d_off, B, shared_scan,
-                                         (const double *)ctx->d_init, (ndt_result *)ctx->d_res, d_trace,
-                                         trace_cap, d_rows);
+  launch_align(map, st, (const float *)ctx->d_scan, (const unsigned long long *)ctx->d_off, B, shared_scan,
+               (const double *)ctx->d_init, (ndt_result *)ctx->d_res, d_trace, trace_cap, d_rows, d_prof);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+  if (want_prof) {
+    unsigned long long *hp = (unsigned long long *)malloc((size_t)B * 32);
+    HIP_TRY(ctx, hipMemcpy(hp, d_prof, (size_t)B * 32, hipMemcpyDeviceToHost));
+    double te = 0, ta = 0, tf = 0, ev = 0, worst = 0;
+    for (int b = 0; b < B; ++b) {
+      te += hp[4 * b] * 0.01; ta += hp[4 * b + 1] * 0.01; tf += hp[4 * b + 2] * 0.01; ev += hp[4 * b + 3];
+      double tot = (hp[4 * b] + hp[4 * b + 1] + hp[4 * b + 2]) * 0.01;
+      if (tot > worst) worst = tot;
+    }
+    fprintf(stderr, "[NDT_PROF] B=%d evals=%.0f | per eval: pass+reduce %.2f us, advance %.2f us | fitness %.2f us/scan | slowest scan %.1f us\n",
+            B, ev, te / ev, ta / ev, tf / B, worst);
+    free(hp);
+    hipError_t e = hipFree(d_prof); (void)e;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_res, (size_t)B * sizeof(ndt_result), hipMemcpyDeviceToHost, st));
   if (d_trace) {
     HIP_TRY(ctx, hipMemcpyAsync(trace, d_trace, (size_t)B * trace_cap * 64, hipMemcpyDeviceToHost, st));
@@ -1299,8 +1669,15 @@ int ndt_eval_at(ndt_ctx *ctx, const ndt_map *map, const float *scan, size_t n, s
   if ((rc = ensure(ctx, &ctx->d_scan, &ctx->d_scan_cap, n * stride))) return rc;
   if ((rc = ensure(ctx, &ctx->d_tmp, &ctx->d_tmp_cap, (size_t)grid * kAcc * 8))) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scan, scan, n * stride, hipMemcpyHostToDevice, st));
-  ndt_eval_kernel<<<grid, 256, 0, st>>>(map->view, map->prm.snap_thresh, (const float *)ctx->d_scan, stride,
-                                        (int)n, p[0], p[1], p[2], (double *)ctx->d_tmp);
+  {
+    const bool sse = map->prm.transform_sse != 0, incl = map->prm.radius_inclusive != 0;
+    const MapView &V = map->view; const double sn = map->prm.snap_thresh;
+    const float *ds = (const float *)ctx->d_scan; double *dt = (double *)ctx->d_tmp;
+    if (sse && incl)       ndt_eval_kernel<true, true><<<grid, 256, 0, st>>>(V, sn, ds, stride, (int)n, p[0], p[1], p[2], dt);
+    else if (sse)          ndt_eval_kernel<true, false><<<grid, 256, 0, st>>>(V, sn, ds, stride, (int)n, p[0], p[1], p[2], dt);
+    else if (incl)         ndt_eval_kernel<false, true><<<grid, 256, 0, st>>>(V, sn, ds, stride, (int)n, p[0], p[1], p[2], dt);
+    else                   ndt_eval_kernel<false, false><<<grid, 256, 0, st>>>(V, sn, ds, stride, (int)n, p[0], p[1], p[2], dt);
+  }
   HIP_TRY(ctx, hipGetLastError());
   double *hp = (double *)malloc((size_t)grid * kAcc * 8);
   if (!hp) return NDT_E_NOMEM;
