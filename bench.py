@@ -95,8 +95,8 @@ def main():
         map_ms.append(ctx.last_timing()[0])
         # a3-a9 for the whole batch: one launch on torch's current stream
         ev_a[2 * i].record(stream)
-        gmap.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, d_init.data_ptr(), d_res.data_ptr(),
-                             stream=stream.cuda_stream)
+        gmap.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, len(scans), d_init.data_ptr(),
+                             d_res.data_ptr(), stream=stream.cuda_stream)
         ev_a[2 * i + 1].record(stream)
         if world > 1:    # gather of poses (the only collective on this path)
             dist.gather(d_res, gathered, dst=0)
@@ -162,8 +162,8 @@ def main():
         ts = []
         for _ in range(5):
             e0.record(stream)
-            gmap.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), 1, d_init.data_ptr(), one.data_ptr(),
-                                 stream=stream.cuda_stream)
+            gmap.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), 1, int(off[1]), d_init.data_ptr(),
+                                 one.data_ptr(), stream=stream.cuda_stream)
             e1.record(stream)
             torch.cuda.synchronize()
             ts.append(e0.elapsed_time(e1))

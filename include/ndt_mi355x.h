@@ -133,9 +133,11 @@ int ndt_align_batch(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_host
                     const uint64_t *offsets_host, int B, int shared_scan,
                     const double *inits_host /* B x 3 */, ndt_result *out_host /* B */);
 /* Same with every buffer resident in device memory; asynchronous on `stream`
- * (NULL = the context's stream).  out_dev receives B ndt_result records. */
+ * (NULL = the context's stream).  out_dev receives B ndt_result records.  total_points = number
+ * of points in scans_xy_dev (offsets[B]; the host knows it, the offsets live on the device): it
+ * sizes the context's scratch copy in which every scan is kept in the order its lanes walk it. */
 int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_dev,
-                        const uint64_t *offsets_dev, int B, int shared_scan,
+                        const uint64_t *offsets_dev, int B, size_t total_points, int shared_scan,
                         const double *inits_dev, ndt_result *out_dev, void *stream);
 /* As ndt_align_batch, additionally recording per derivative pass of every match
  * 8 doubles {a_t, score, g0, g1, g2, p0, p1, p2} (parity tests: same step sequence as the

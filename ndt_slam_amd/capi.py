@@ -77,7 +77,7 @@ def lib():
     L.ndt_map_export.argtypes = [vp, vp, vp, vp, vp, vp]
     L.ndt_align.argtypes = [vp, vp, vp, sz, sz, vp, vp]
     L.ndt_align_batch.argtypes = [vp, vp, vp, vp, i, i, vp, vp]
-    L.ndt_align_batch_dev.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp]
+    L.ndt_align_batch_dev.argtypes = [vp, vp, vp, vp, i, sz, i, vp, vp, vp]
     L.ndt_align_batch_trace.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, i, vp]
     L.ndt_eval_at.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp, vp, vp]
     L.ndt_fitness_at.argtypes = [vp, vp, vp, sz, sz, C.c_float, C.c_float, C.c_float, C.c_float, vp]
@@ -202,10 +202,12 @@ class Map:
                        "ndt_align_batch")
         return res
 
-    def align_batch_dev(self, scans_ptr, offsets_ptr, B, inits_ptr, out_ptr, shared_scan=False, stream=None):
+    def align_batch_dev(self, scans_ptr, offsets_ptr, B, total_points, inits_ptr, out_ptr, shared_scan=False,
+                        stream=None):
         """All pointers are device addresses (e.g. torch.Tensor.data_ptr()); asynchronous."""
-        self.ctx.check(lib().ndt_align_batch_dev(self.ctx.h, self.h, scans_ptr, offsets_ptr, B, int(shared_scan),
-                                                 inits_ptr, out_ptr, stream), "ndt_align_batch_dev")
+        self.ctx.check(lib().ndt_align_batch_dev(self.ctx.h, self.h, scans_ptr, offsets_ptr, B, total_points,
+                                                 int(shared_scan), inits_ptr, out_ptr, stream),
+                       "ndt_align_batch_dev")
 
     def eval_at(self, scan, p):
         scan = _f32c(scan)

@@ -133,14 +133,15 @@ __device__ __forceinline__ void angle_cs(double snap, double yaw, double &c, dou
 // moves).  Two pieces share one LDS pool: a row-major rw x rh table of 16-bit slot numbers and a
 // compact table of the occupied voxels' records (48 B: float32 centroid, fp64 mean, fp64 inverse
 // covariance), so that the hot loop touches no global memory for map data.
-struct Region { int x0, y0, rw, rh, cap; };   // origin in unpadded voxel coordinates; cap = record slots
+struct Region { int x0, y0, rw, rh, cap, nspill; };   // origin in unpadded voxel coordinates; cap = record slots
 struct __attribute__((aligned(16))) CellEntry { float2 cent; double mx, my, i00, i01, i11; };
 static_assert(sizeof(CellEntry) == 48, "CellEntry layout");
 constexpr int kRegionCells = 16384;           // at most 32 KiB of slot numbers
 constexpr int kRegionMargin = 5;              // cells of slack around the scan's first bbox
 constexpr int kPoolBytes = 156 * 1024;        // of the CU's 160 KiB LDS
-constexpr unsigned kSlotEmpty = 0xFFFFu;      // voxel not in the centroid search set
-constexpr unsigned kSlotSpill = 0xFFFEu;      // record did not fit the LDS pool: read it from HBM
+// A slot number indexes the record table.  Voxels outside the search set point at the sentinel
+// record `cap` (centroid = +inf, so the radius test fails by itself).  If a window holds more
+// occupied voxels than the pool has room for, nspill > 0 and the whole scan reads the map from HBM.
 
 struct Window {
   Region R;
@@ -239,10 +240,32 @@ __device__ __forceinline__ void accumulate_cell(double d2, const double *__restr
   A.htt = __builtin_fma(e, tt, A.htt);
 }
 
+// Number of in-radius voxels of one source point at transform T (same tests as eval_point).
+template <bool SSE, bool INCL>
+__device__ __forceinline__ int count_in_radius(const MapView &M, const Window &W, const Tf32 &T, float x,
+                                               float y) {
+  float xt, yt;
+  tf_apply_t<SSE>(T, x, y, xt, yt);
+  const bool fin = finite2(xt, yt);
+  const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
+  const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
+  const int ix = (int)fx - M.min_bx, iy = (int)fy - M.min_by;
+  const bool ingrid = fin & (ix >= -1) & (ix <= M.div_x) & (iy >= -1) & (iy <= M.div_y);
+  if (!ingrid) return 0;
+  const float2 *grow = M.cent + (size_t)(iy + 1) * M.gw + (ix + 1);
+  unsigned mask = 0;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) mask |= in_radius<INCL>(M.r2, xt, yt, grow[r * M.gw + q]) << (r * 3 + q);
+  (void)W;
+  return __builtin_popcount(mask);
+}
+
 // Everything one source point contributes to a derivative pass.
-// Fast path (point's 3x3 neighbourhood inside the LDS window, no spilled record among its
-// candidates): slot numbers, centroids and records all come from LDS.  Otherwise the same
-// arithmetic reads the global centroid grid / record array.
+// Fast path (window holds every occupied voxel, point's 3x3 neighbourhood inside it): slot
+// numbers, centroids and records all come from LDS.  Otherwise the same arithmetic reads the
+// global centroid grid / record array.
 template <bool SSE, bool INCL>
 __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
                                            const double *__restrict__ etab, const Tf32 &T, float x,
@@ -256,22 +279,17 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
   const bool ingrid = fin & (ix >= -1) & (ix <= M.div_x) & (iy >= -1) & (iy <= M.div_y);
   const Region &R = W.R;
   const int lx = ix - R.x0, ly = iy - R.y0;
-  const bool inwin = ingrid & (lx >= 1) & (lx < R.rw - 1) & (ly >= 1) & (ly < R.rh - 1);
+  const bool inwin = ingrid & (R.nspill == 0) & (lx >= 1) & (lx < R.rw - 1) & (ly >= 1) & (ly < R.rh - 1);
   // LDS probes with clamped indices (results dropped when !inwin)
   const int clx = min(max(lx, 1), max(R.rw - 2, 1)), cly = min(max(ly, 1), max(R.rh - 2, 1));
   const unsigned short *srow = W.slot + (cly - 1) * R.rw + (clx - 1);
-  unsigned mask = 0, spill = 0;
+  unsigned mask = 0;
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const unsigned sl = srow[r * R.rw + q];
-      const bool member = sl < kSlotSpill;
-      spill |= (sl == kSlotSpill) ? 1u : 0u;
-      const float2 cc = W.ent[member ? sl : 0u].cent;
-      mask |= (member ? in_radius<INCL>(M.r2, xt, yt, cc) : 0u) << (r * 3 + q);
-    }
-  if (inwin & !spill) {
+    for (int q = 0; q < 3; ++q)
+      mask |= in_radius<INCL>(M.r2, xt, yt, W.ent[srow[r * R.rw + q]].cent) << (r * 3 + q);
+  if (inwin) {
     if (!mask) return;
     A.pairs += __builtin_popcount(mask);
     const PointTerms P = point_terms(x, y, xt, yt, cj, sj, ch, sh);
@@ -385,6 +403,20 @@ __device__ __forceinline__ void solve3(const double Hs[6], double b0, double b1,
   if (a00 != a00 || a01 != a01 || a02 != a02 || a11 != a11 || a12 != a12 || a22 != a22) {
     x0 = x1 = x2 = NAN; return;
   }
+  {
+    // well-conditioned case: adjugate / determinant
+    const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    const double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+    const double det = a00 * c00 + a01 * c01 + a02 * c02;
+    const double sc = fmax(fmax(fabs(a00), fabs(a11)), fmax(fabs(a22), fmax(fabs(a01), fmax(fabs(a02), fabs(a12)))));
+    if (fabs(det) > 1e-9 * sc * sc * sc && fabs(det) <= DBL_MAX) {
+      x0 = (c00 * b0 + c01 * b1 + c02 * b2) / det;
+      x1 = (c01 * b0 + c11 * b1 + c12 * b2) / det;
+      x2 = (c02 * b0 + c12 * b1 + c22 * b2) / det;
+      return;
+    }
+  }
+  // near-singular Hessian: pseudo-inverse through the eigen-decomposition
   double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;
   for (int sweep = 0; sweep < 12; ++sweep) {
     const double off = fabs(a01) + fabs(a02) + fabs(a12);
@@ -670,7 +702,7 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
 // ------------------------------------------------------------------------------------------
 // the match kernel: one workgroup per scan, the whole optimisation on the device
 // ------------------------------------------------------------------------------------------
-constexpr int kBlock = 512;
+constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / 64;
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -690,6 +722,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
                  const unsigned long long *__restrict__ offsets, int B, int shared_scan,
                  const double *__restrict__ inits, ndt_result *__restrict__ results,
                  double *__restrict__ trace, int trace_cap, int *__restrict__ trace_rows,
+                 float2 *__restrict__ sorted /* scratch, same offsets as scans; may be null */,
                  unsigned long long *__restrict__ prof /* diagnostic: 4 x ticks per scan */) {
   __shared__ AlignState S;
   __shared__ double sred[(kWaves + 1) * kAcc];
@@ -734,7 +767,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       }
       __syncthreads();
       if (threadIdx.x == 0) {
-        Region r = {0, 0, 0, 0, 0};
+        Region r = {0, 0, 0, 0, 0, 0};
         if (sbox[0] <= sbox[2]) {
           // clip the bbox to the padded map grid, add the slack, then fit the slot-table budget
           // around the bbox centre
@@ -753,8 +786,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
           }
         }
         const int slot_bytes = ((r.rw * r.rh * 2 + 15) / 16) * 16;
-        int cap = (kPoolBytes - slot_bytes) / (int)sizeof(CellEntry) - 1;
-        r.cap = cap > (int)kSlotSpill - 1 ? (int)kSlotSpill - 1 : cap;
+        int cap = (kPoolBytes - slot_bytes) / (int)sizeof(CellEntry) - 1;   // last one = sentinel
+        r.cap = cap > 0xFFFF ? 0xFFFF : cap;
         RG = r;
       }
       __syncthreads();
@@ -784,22 +817,20 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       int next = swave[threadIdx.x >> 6] + incl - mine;
       if (threadIdx.x == 0) {
         CellEntry z; z.cent = make_float2(INFINITY, INFINITY); z.mx = z.my = z.i00 = z.i01 = z.i11 = 0.0;
-        ent[r.cap] = z;                          // never indexed by a slot; keeps slot 0 reads defined when empty
-        if (swave[kWaves] == 0) ent[0] = z;
+        ent[r.cap] = z;                          // sentinel record of the voxels outside the search set
+        RG.nspill = swave[kWaves] > r.cap ? swave[kWaves] - r.cap : 0;
       }
       for (int c = c0; c < c1; ++c) {
         const int ly = c / r.rw, lx = c - ly * r.rw;
         const size_t pg = (size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2);
         const float2 cc = M.cent[pg];
-        unsigned sl = kSlotEmpty;
+        unsigned sl = (unsigned)r.cap;
         if (cc.x < INFINITY) {
           if (next < r.cap) {
             const double *rec = M.rec + pg * 8;
             CellEntry E; E.cent = cc; E.mx = rec[0]; E.my = rec[1]; E.i00 = rec[2]; E.i01 = rec[3]; E.i11 = rec[4];
             ent[next] = E;
             sl = (unsigned)next;
-          } else {
-            sl = kSlotSpill;
           }
           ++next;
         }
@@ -812,6 +843,46 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     W.slot = reinterpret_cast<const unsigned short *>(pool);
     W.ent = reinterpret_cast<const CellEntry *>(reinterpret_cast<const char *>(pool) +
                                                 ((W.R.rw * W.R.rh * 2 + 15) / 16) * 16);
+    // ---- order every lane's own points by their in-radius voxel count at the first pose ----
+    // A wave walks its 64 lanes' k-th points together and runs the pair body max-over-lanes times,
+    // so lanes should meet points of equal count at equal k.  Each lane counting-sorts its own
+    // points (descending count, stable) in groups of 32 and writes them, lane-contiguous, to the
+    // scratch copy the passes then read.  No cross-lane traffic; the order depends only on the
+    // scan, the map and the initial pose.
+    const float2 *pts = scan;
+    if (sorted && !shared_scan) {
+      float2 *sp = sorted + o0;
+      const Tf32 T0 = S.T;
+      for (int g0 = 0; g0 * kBlock + (int)threadIdx.x < n; g0 += 32) {
+        unsigned long long k_lo = 0, k_hi = 0, hist = 0;   // 4-bit counts of 32 points; 6-bit histogram fields
+        int cnt = 0;
+#pragma nounroll
+        for (int jj = 0; jj < 32; ++jj) {
+          const int i = (g0 + jj) * kBlock + threadIdx.x;
+          if (i >= n) break;
+          const float2 pt = scan[i];
+          const unsigned long long K = (unsigned long long)count_in_radius<SSE, INCL>(M, W, T0, pt.x, pt.y);
+          if (jj < 16) k_lo |= K << (4 * jj); else k_hi |= K << (4 * (jj - 16));
+          hist += 1ull << (6 * K);
+          ++cnt;
+        }
+        unsigned long long starts = 0; unsigned run = 0;
+#pragma unroll
+        for (int kk = 9; kk >= 0; --kk) {                   // descending count
+          starts |= (unsigned long long)run << (6 * kk);
+          run += (unsigned)((hist >> (6 * kk)) & 63ull);
+        }
+#pragma nounroll
+        for (int jj = 0; jj < cnt; ++jj) {
+          const unsigned K = (unsigned)(((jj < 16) ? (k_lo >> (4 * jj)) : (k_hi >> (4 * (jj - 16)))) & 15ull);
+          const unsigned pos = (unsigned)((starts >> (6 * K)) & 63ull);
+          starts += 1ull << (6 * K);
+          sp[(size_t)(g0 + (int)pos) * kBlock + threadIdx.x] = scan[(g0 + jj) * kBlock + threadIdx.x];
+        }
+      }
+      pts = sp;
+      __syncthreads();
+    }
     unsigned long long t_eval = 0, t_adv = 0, t0 = 0, t1 = 0;
     // ---- optimisation loop: every iteration is one derivative pass (HOT LOOP A+B fused) ----
     for (;;) {
@@ -824,10 +895,10 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       {
         const int last = n - 1;
         int i = threadIdx.x;
-        float2 p0 = scan[min(i, last)], p1 = scan[min(i + kBlock, last)];
+        float2 p0 = pts[min(i, last)], p1 = pts[min(i + kBlock, last)];
 #pragma nounroll
         for (; i < n; i += kBlock) {
-          const float2 p2 = scan[min(i + 2 * kBlock, last)];
+          const float2 p2 = pts[min(i + 2 * kBlock, last)];
           eval_point<SSE, INCL>(M, W, etab, T, p0.x, p0.y, cj, sj, ch, sh, A);
           p0 = p1; p1 = p2;
         }
@@ -850,7 +921,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       float best = nearest_sq(M, qx, qy);
       if (best < INFINITY) { fsum += (double)best; fcnt += 1.0; }
     };
-    for (int i = threadIdx.x; i < n; i += kBlock) { float2 pt = scan[i]; fit(pt.x, pt.y); }
+    for (int i = threadIdx.x; i < n; i += kBlock) { float2 pt = pts[i]; fit(pt.x, pt.y); }
     block_reduce2(fsum, fcnt, sred);
     if (threadIdx.x == 0) {
       const double fs[2] = {sred[kWaves * 2], sred[kWaves * 2 + 1]};
@@ -890,7 +961,7 @@ ndt_eval_kernel(MapView M, double snap, const float *__restrict__ scan, size_t s
   __shared__ unsigned short no_slot[16];
   __shared__ CellEntry no_ent[1];
   if (threadIdx.x < 64) etab[threadIdx.x] = c_exp2_tab[threadIdx.x];
-  if (threadIdx.x < 16) no_slot[threadIdx.x] = (unsigned short)kSlotEmpty;
+  if (threadIdx.x < 16) no_slot[threadIdx.x] = 0;
   if (threadIdx.x == 0) { no_ent[0].cent = make_float2(INFINITY, INFINITY); no_ent[0].mx = no_ent[0].my = 0; no_ent[0].i00 = no_ent[0].i01 = no_ent[0].i11 = 0; }
   __syncthreads();
   double p[3] = {p0, p1, p2};
@@ -899,7 +970,7 @@ ndt_eval_kernel(MapView M, double snap, const float *__restrict__ scan, size_t s
   angle_cs(snap, p2, cj, sj);
   Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
   Window W;
-  W.R = Region{0, 0, 0, 0, 0}; W.slot = no_slot; W.ent = no_ent;
+  W.R = Region{0, 0, 0, 0, 0, 0}; W.slot = no_slot; W.ent = no_ent;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float2 pt = load_pt(scan, stride, i);
     eval_point<SSE, INCL>(M, W, etab, T, pt.x, pt.y, cj, sj, cj, sj, A);
@@ -1214,6 +1285,7 @@ struct ndt_ctx {
   void *d_tmp = nullptr; size_t d_tmp_cap = 0;
   void *d_trace = nullptr; size_t d_trace_cap = 0;
   void *d_rows = nullptr; size_t d_rows_cap = 0;
+  void *d_sorted = nullptr; size_t d_sorted_cap = 0;   // per-lane ordered copy of the scans
 };
 
 struct ndt_map {
@@ -1297,13 +1369,13 @@ int grid_for(size_t n, int block, int cap = 2048) {
 
 void launch_align(const ndt_map *map, hipStream_t st, const float *scans, const unsigned long long *offsets,
                   int B, int shared_scan, const double *inits, ndt_result *out, double *trace, int trace_cap,
-                  int *trace_rows, unsigned long long *prof) {
+                  int *trace_rows, float2 *sorted, unsigned long long *prof) {
   const bool sse = map->prm.transform_sse != 0, incl = map->prm.radius_inclusive != 0;
   const MapView &V = map->view;
   const OptParams O = opt_of(map->prm);
 #define NDT_LAUNCH(S_, I_)                                                                           \
   ndt_align_kernel<S_, I_><<<B, kBlock, 0, st>>>(V, O, scans, offsets, B, shared_scan, inits, out, trace, \
-                                                 trace_cap, trace_rows, prof)
+                                                 trace_cap, trace_rows, sorted, prof)
   if (sse && incl) NDT_LAUNCH(true, true);
   else if (sse)    NDT_LAUNCH(true, false);
   else if (incl)   NDT_LAUNCH(false, true);
@@ -1363,7 +1435,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->own_stream) e = hipStreamDestroy(c->own_stream);
   if (c->ev0) e = hipEventDestroy(c->ev0);
   if (c->ev1) e = hipEventDestroy(c->ev1);
-  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows};
+  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
   delete c;
@@ -1561,13 +1633,20 @@ int ndt_map_export(const ndt_map *cm, int *cell_idx, float *cent_xy, double *mea
 }
 
 int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, const uint64_t *offsets,
-                        int B, int shared_scan, const double *inits, ndt_result *out, void *stream) {
+                        int B, size_t total_points, int shared_scan, const double *inits, ndt_result *out,
+                        void *stream) {
   if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
   if (!map || !scans || !offsets || !inits || !out || B <= 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: bad arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  float2 *sorted = nullptr;
+  if (!shared_scan && total_points > 0) {
+    int rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, total_points * 8);
+    if (rc) return rc;
+    sorted = (float2 *)ctx->d_sorted;
+  }
   launch_align(map, st, scans, (const unsigned long long *)offsets, B, shared_scan, inits, out, nullptr, 0,
-               nullptr, nullptr);
+               nullptr, sorted, nullptr);
   HIP_TRY(ctx, hipGetLastError());
   return NDT_OK;
 }
@@ -1604,8 +1683,13 @@ int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, 
   const bool want_prof = getenv("NDT_PROF") != nullptr;
   if (want_prof) HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 32));
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+  float2 *sorted = nullptr;
+  if (!shared_scan) {
+    if ((rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (size_t)offsets[nscan] * 8))) return rc;
+    sorted = (float2 *)ctx->d_sorted;
+  }
   launch_align(map, st, (const float *)ctx->d_scan, (const unsigned long long *)ctx->d_off, B, shared_scan,
-               (const double *)ctx->d_init, (ndt_result *)ctx->d_res, d_trace, trace_cap, d_rows, d_prof);
+               (const double *)ctx->d_init, (ndt_result *)ctx->d_res, d_trace, trace_cap, d_rows, sorted, d_prof);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
   if (want_prof) {

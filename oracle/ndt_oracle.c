@@ -434,6 +434,20 @@ void ndt_oracle_solve3(const double Hin[9], const double b[3], double x[3]) {
   double A[3][3], V[3][3];
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { A[i][j] = 0.5 * (Hin[3 * i + j] + Hin[3 * j + i]); V[i][j] = (i == j); }
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) if (A[i][j] != A[i][j]) { x[0] = x[1] = x[2] = NAN; return; }
+  {
+    /* well-conditioned case: adjugate / determinant (same answer as the SVD solve up to rounding) */
+    double a00 = A[0][0], a01 = A[0][1], a02 = A[0][2], a11 = A[1][1], a12 = A[1][2], a22 = A[2][2];
+    double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+    double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+    double det = a00 * c00 + a01 * c01 + a02 * c02;
+    double sc = fmax(fmax(fabs(a00), fabs(a11)), fmax(fabs(a22), fmax(fabs(a01), fmax(fabs(a02), fabs(a12)))));
+    if (fabs(det) > 1e-9 * sc * sc * sc && fabs(det) <= DBL_MAX) {
+      x[0] = (c00 * b[0] + c01 * b[1] + c02 * b[2]) / det;
+      x[1] = (c01 * b[0] + c11 * b[1] + c12 * b[2]) / det;
+      x[2] = (c02 * b[0] + c12 * b[1] + c22 * b[2]) / det;
+      return;
+    }
+  }
   for (int sweep = 0; sweep < 12; ++sweep) {
     double off = fabs(A[0][1]) + fabs(A[0][2]) + fabs(A[1][2]);
     if (off == 0.0) break;
