@@ -138,7 +138,7 @@ struct __attribute__((aligned(16))) CellEntry { float2 cent; double mx, my, i00,
 static_assert(sizeof(CellEntry) == 48, "CellEntry layout");
 constexpr int kRegionCells = 16384;           // at most 32 KiB of slot numbers
 constexpr int kRegionMargin = 5;              // cells of slack around the scan's first bbox
-constexpr int kPoolBytes = 156 * 1024;        // of the CU's 160 KiB LDS
+constexpr int kPoolBytes = 147 * 1024;        // of the CU's 160 KiB LDS
 // A slot number indexes the record table.  Voxels outside the search set point at the sentinel
 // record `cap` (centroid = +inf, so the radius test fails by itself).  If a window holds more
 // occupied voxels than the pool has room for, nspill > 0 and the whole scan reads the map from HBM.
@@ -279,17 +279,21 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
   const bool ingrid = fin & (ix >= -1) & (ix <= M.div_x) & (iy >= -1) & (iy <= M.div_y);
   const Region &R = W.R;
   const int lx = ix - R.x0, ly = iy - R.y0;
-  const bool inwin = ingrid & (R.nspill == 0) & (lx >= 1) & (lx < R.rw - 1) & (ly >= 1) & (ly < R.rh - 1);
+  const bool inwin = ingrid & (lx >= 1) & (lx < R.rw - 1) & (ly >= 1) & (ly < R.rh - 1);
   // LDS probes with clamped indices (results dropped when !inwin)
   const int clx = min(max(lx, 1), max(R.rw - 2, 1)), cly = min(max(ly, 1), max(R.rh - 2, 1));
   const unsigned short *srow = W.slot + (cly - 1) * R.rw + (clx - 1);
   unsigned mask = 0;
+  float lowx = INFINITY;                       // -inf <=> one of the nine voxels is occupied but not resident
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-      mask |= in_radius<INCL>(M.r2, xt, yt, W.ent[srow[r * R.rw + q]].cent) << (r * 3 + q);
-  if (inwin) {
+    for (int q = 0; q < 3; ++q) {
+      const float2 cc = W.ent[srow[r * R.rw + q]].cent;
+      lowx = fminf(lowx, cc.x);
+      mask |= in_radius<INCL>(M.r2, xt, yt, cc) << (r * 3 + q);
+    }
+  if (inwin & (lowx != -INFINITY)) {
     if (!mask) return;
     A.pairs += __builtin_popcount(mask);
     const PointTerms P = point_terms(x, y, xt, yt, cj, sj, ch, sh);
@@ -333,18 +337,18 @@ __device__ __forceinline__ double wave_sum(double x) {
 }
 
 template <int NV>
-__device__ __forceinline__ void block_combine(double *sred) {
+__device__ __forceinline__ void block_combine(double *sred, double *out) {
   const int nw = blockDim.x >> 6;
   __syncthreads();
   if (threadIdx.x < NV) {
     double s = 0.0;
     for (int w = 0; w < nw; ++w) s += sred[w * NV + threadIdx.x];
-    sred[nw * NV + threadIdx.x] = s;
+    out[threadIdx.x] = s;
   }
   __syncthreads();
 }
 
-__device__ __forceinline__ void block_reduce_acc(const Acc &A, double *sred) {
+__device__ __forceinline__ void block_reduce_acc(const Acc &A, double *sred, double *out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double *row = sred + wave * kAcc;
   double t;
@@ -360,16 +364,16 @@ __device__ __forceinline__ void block_reduce_acc(const Acc &A, double *sred) {
   t = wave_sum(A.hyt);   if (lane == 0) row[8] = t;
   t = wave_sum(A.htt);   if (lane == 0) row[9] = t;
   t = wave_sum((double)A.pairs); if (lane == 0) row[10] = t;
-  block_combine<kAcc>(sred);
+  block_combine<kAcc>(sred, out);
 }
 
-__device__ __forceinline__ void block_reduce2(double a, double b, double *sred) {
+__device__ __forceinline__ void block_reduce2(double a, double b, double *sred, double *out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double t;
   __syncthreads();
   t = wave_sum(a); if (lane == 0) sred[wave * 2 + 0] = t;
   t = wave_sum(b); if (lane == 0) sred[wave * 2 + 1] = t;
-  block_combine<2>(sred);
+  block_combine<2>(sred, out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -496,7 +500,7 @@ __device__ __forceinline__ void set_trial(AlignState &S, const OptParams &P, boo
 
 // Start (or finish) outer iterations until a derivative pass is needed or the match is done.
 __device__ __noinline__ void begin_outer(AlignState &S, const OptParams &P) {
-  for (;;) {
+  for (int guard = 0; guard < 1 << 20; ++guard) {   // every turn either asks for a pass or counts an iteration
     double dp0, dp1, dp2;
     solve3(S.H, -S.g[0], -S.g[1], -S.g[2], dp0, dp1, dp2);
     double nrm = sqrt(dp0 * dp0 + dp1 * dp1 + dp2 * dp2);
@@ -683,14 +687,20 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
   for (int r = 1; r <= rmax; ++r) {
     const double bound = (double)r * Ld * 0.999;        // unvisited points are farther than r*L
     if ((double)best <= bound * bound) break;
-    const int R = r + 1;                                // visit the whole ring R
-    const int y0 = cy - R, y1 = cy + R, x0 = cx - R, x1 = cx + R;
-    for (int yy = (y0 < 0 ? 0 : y0); yy <= y1 && yy < M.div_y; ++yy) {
+    const int R = r + 1;                                // ring R, pruned by box distances: in a row at
+    const int y0 = cy - R, y1 = cy + R, x0 = cx - R, x1 = cx + R;   // distance by only the columns whose
+    for (int yy = (y0 < 0 ? 0 : y0); yy <= y1 && yy < M.div_y; ++yy) {   // box is nearer than sqrt(best - by^2)
+      const int dyc = yy - cy;
+      const float by = dyc < 0 ? wd + (float)(-dyc - 1) * L : (dyc > 0 ? wu + (float)(dyc - 1) * L : 0.f);
+      const float rem = best - by * by;
+      if (!(rem > 0.f)) continue;
+      const int hw = (int)fminf(sqrtf(rem) / L, 1.0e6f) + 1;   // columns farther than hw cannot matter
       const size_t g = (size_t)yy * M.div_x;
       if (yy == y0 || yy == y1) {
-        const int xa = x0 < 0 ? 0 : x0, xb = x1 >= M.div_x ? M.div_x - 1 : x1;
+        int xa = x0 > cx - hw ? x0 : cx - hw, xb = x1 < cx + hw ? x1 : cx + hw;
+        xa = xa < 0 ? 0 : xa; xb = xb >= M.div_x ? M.div_x - 1 : xb;
         if (xa <= xb) best = scan_bucket(M.pts, ps[g + xa], ps[g + xb + 1], qx, qy, best);
-      } else {
+      } else if (R <= hw) {
         if (x0 >= 0 && x0 < M.div_x) best = scan_bucket(M.pts, ps[g + x0], ps[g + x0 + 1], qx, qy, best);
         if (x1 >= 0 && x1 < M.div_x) best = scan_bucket(M.pts, ps[g + x1], ps[g + x1 + 1], qx, qy, best);
       }
@@ -700,10 +710,67 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
 }
 
 // ------------------------------------------------------------------------------------------
-// the match kernel: one workgroup per scan, the whole optimisation on the device
+// the match kernel
+//
+// One workgroup per CU.  Every scan has an OWNER workgroup that holds the optimiser state in LDS
+// and runs the whole match on the device.  A derivative pass (and the fitness pass) is cut into
+// chunks of kChunkPts points; each chunk is reduced on its own and the pass total is the sum of
+// the chunk totals in chunk order, so the result does not depend on who computed which chunk.
+// A workgroup whose own scans are finished becomes a HELPER: it attaches to an unfinished scan,
+// stages that scan's window in its own LDS and claims chunks of that scan's passes.  Matches
+// differ widely in the number of passes they need (mean ~12, max ~40 on the bench workload), so
+// without helpers most of the chip idles behind the slowest scans.
+//
+// Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16): every shared word (ticket,
+// arrival counter, pose block, chunk totals) is read and written ONLY with agent-scope relaxed
+// atomics (sc1 loads / write-through stores), payload stores are drained (s_waitcnt vmcnt(0))
+// before the word that signals them, and the one bulk hand-off (the owner's ordered scan copy and
+// window geometry) uses plain stores + agent release fence on the owner and an agent acquire
+// fence on the helper.  No workgroup ever waits for a specific other workgroup to be scheduled:
+// owners only wait for chunks that some running workgroup has already claimed, helpers only poll.
+// Every spin is bounded by a watchdog that raises the abort word.
 // ------------------------------------------------------------------------------------------
 constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / 64;
+constexpr int kSub = 4;                      // a lane's points are cut into kSub runs -> kSub units per wave
+constexpr int kUnits = kWaves * kSub;        // units per pass
+constexpr int kMaxHelpers = 7;               // helper workgroups per scan (16 units: 2 each)
+constexpr unsigned kEpochDone = 0xFFFFFFFFu;
+constexpr unsigned long long kWatchTicks = 400000000ull;   // ~4 s of the 100 MHz wall clock
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// Per-scan control block: four 128-byte lines, so that the words hammered by different parties
+// (chunk claims and epoch polls / arrivals / attach counts / pose reads) never share a line.
+struct alignas(128) ScanCtl {
+  u64 ticket;        // line 0: (epoch << 32) | next chunk.  epoch 0: not open; kEpochDone: finished
+  u64 pad0_[15];
+  u32 arrive;        // line 1: chunks published by helpers in the open epoch
+  u32 pad1_[31];
+  u32 helpers;       // line 2: helper workgroups attached; geometry published by the owner's release
+  int region[6];
+  u32 passes;        //         passes the owner has run so far (helpers go where most were needed)
+  int pad2_[24];
+  u64 pose[6];       // line 3: float32 transform (c|s, tx|ty) and the four fp64 angle terms
+  u64 kind;          //         0: derivative pass, 1: fitness pass
+  u64 pad3_[9];
+};
+static_assert(sizeof(ScanCtl) == 512, "ScanCtl is four 128-byte lines");
+
+struct WsHeader { u32 done; u32 abort; u32 pad[30]; };
+static_assert(sizeof(WsHeader) == 128, "WsHeader");
+
+#define NDT_RLX __ATOMIC_RELAXED
+#define NDT_AGENT __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ u64 ld64(const u64 *p) { return __hip_atomic_load(p, NDT_RLX, NDT_AGENT); }
+__device__ __forceinline__ u32 ld32(const u32 *p) { return __hip_atomic_load(p, NDT_RLX, NDT_AGENT); }
+__device__ __forceinline__ void st64(u64 *p, u64 v) { __hip_atomic_store(p, v, NDT_RLX, NDT_AGENT); }
+__device__ __forceinline__ void st32(u32 *p, u32 v) { __hip_atomic_store(p, v, NDT_RLX, NDT_AGENT); }
+// reads through a memory-side read-modify-write: never served from a stale L2 line of this XCD
+__device__ __forceinline__ u64 rd64_fresh(u64 *p) { return __hip_atomic_fetch_add(p, 0ull, NDT_RLX, NDT_AGENT); }
+__device__ __forceinline__ u32 rd32_fresh(u32 *p) { return __hip_atomic_fetch_add(p, 0u, NDT_RLX, NDT_AGENT); }
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -716,6 +783,318 @@ __device__ __forceinline__ int wave_max_i(int v) {
   return v;
 }
 
+// pose block of the pass being computed (LDS copy)
+struct PassPose { Tf32 T; double cj, sj, ch, sh; int kind; };
+
+struct Lds {
+  AlignState S;
+  PassPose PP;
+  Region RG;
+  int sbox[4];
+  int swave[kWaves + 1];
+  int sflag[4];
+  double wpart[kUnits * 12];       // unit totals this workgroup computed in the open pass
+  double wtmp[kWaves * 12];        // helper waves: the unit just computed, before it is published
+  double tot[12];                  // pass totals
+  unsigned long long own_mask;     // units of the open pass computed by this workgroup
+  double etab[64];
+};
+
+__device__ __forceinline__ Window window_of(const Region &R, const uint4 *pool) {
+  Window W;
+  W.R = R;
+  W.slot = reinterpret_cast<const unsigned short *>(pool);
+  W.ent = reinterpret_cast<const CellEntry *>(reinterpret_cast<const char *>(pool) +
+                                              ((R.rw * R.rh * 2 + 15) / 16) * 16);
+  return W;
+}
+
+// Owner: bounding box of the scan's voxel coordinates at the first pose -> window geometry.
+template <bool SSE>
+__device__ __forceinline__ void compute_region(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
+                                               int n, Lds &L) {
+  if (threadIdx.x == 0) { L.sbox[0] = INT_MAX; L.sbox[1] = INT_MAX; L.sbox[2] = INT_MIN; L.sbox[3] = INT_MIN; }
+  __syncthreads();
+  int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    const float2 pt = scan[i];
+    float xt, yt;
+    tf_apply_t<SSE>(T0, pt.x, pt.y, xt, yt);
+    if (!finite2(xt, yt)) continue;
+    const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const int ix = (int)fx - M.min_bx, iy = (int)fy - M.min_by;
+    mnx = ix < mnx ? ix : mnx; mxx = ix > mxx ? ix : mxx;
+    mny = iy < mny ? iy : mny; mxy = iy > mxy ? iy : mxy;
+  }
+  mnx = wave_min_i(mnx); mny = wave_min_i(mny); mxx = wave_max_i(mxx); mxy = wave_max_i(mxy);
+  if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
+    atomicMin(&L.sbox[0], mnx); atomicMin(&L.sbox[1], mny); atomicMax(&L.sbox[2], mxx); atomicMax(&L.sbox[3], mxy);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Region r = {0, 0, 0, 0, 0, 0};
+    if (L.sbox[0] <= L.sbox[2]) {
+      // clip the bbox to the padded map grid, add the slack, then fit the slot-table budget around
+      // the bbox centre
+      long long x0 = (long long)L.sbox[0] - kRegionMargin, x1 = (long long)L.sbox[2] + kRegionMargin;
+      long long y0 = (long long)L.sbox[1] - kRegionMargin, y1 = (long long)L.sbox[3] + kRegionMargin;
+      x0 = x0 < -2 ? -2 : x0; y0 = y0 < -2 ? -2 : y0;
+      x1 = x1 > M.div_x + 1 ? M.div_x + 1 : x1; y1 = y1 > M.div_y + 1 ? M.div_y + 1 : y1;
+      long long w = x1 - x0 + 1, h = y1 - y0 + 1;
+      if (w > 0 && h > 0) {
+        if (w * h > kRegionCells) {
+          long long w2 = w > 128 ? 128 : w;
+          long long h2 = kRegionCells / w2; if (h2 > h) h2 = h;
+          x0 += (w - w2) / 2; y0 += (h - h2) / 2; w = w2; h = h2;
+        }
+        r.x0 = (int)x0; r.y0 = (int)y0; r.rw = (int)w; r.rh = (int)h;
+      }
+    }
+    const int slot_bytes = ((r.rw * r.rh * 2 + 15) / 16) * 16;
+    int cap = (kPoolBytes - slot_bytes) / (int)sizeof(CellEntry) - 2;   // last two = sentinels
+    r.cap = cap > 0xFFF0 ? 0xFFF0 : cap;
+    L.RG = r;
+  }
+  __syncthreads();
+}
+
+// Owner: mark the window cells the scan's points fall in at the first pose (one bit per cell,
+// kept in L.wmap).  fill_window gives LDS records only to occupied voxels within 2 cells of a
+// marked one (the voxels the scan can reach while its pose moves by up to ~1 m); a point that
+// later needs any other occupied voxel takes the HBM path for that pass.
+template <bool SSE>
+__device__ __forceinline__ void mark_wanted(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
+                                            int n, Lds &L) {
+  unsigned *wmap = reinterpret_cast<unsigned *>(L.wpart);
+  for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) wmap[i] = 0u;
+  __syncthreads();
+  const Region r = L.RG;
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    const float2 pt = scan[i];
+    float xt, yt;
+    tf_apply_t<SSE>(T0, pt.x, pt.y, xt, yt);
+    if (!finite2(xt, yt)) continue;
+    const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const int lx = (int)fx - M.min_bx - r.x0, ly = (int)fy - M.min_by - r.y0;
+    if (lx < 0 || lx >= r.rw || ly < 0 || ly >= r.rh) continue;
+    const int bit = ly * r.rw + lx;
+    atomicOr(&wmap[bit >> 5], 1u << (bit & 31));
+  }
+  __syncthreads();
+}
+
+// Owner and helpers: fill the slot table and the compact record table of window L.RG from the map
+// and the marked-cell bitmap in L.wmap.  Slots are numbered in row-major order of the window, so
+// the content depends only on the map, the geometry and the bitmap.  Slot values: < cap a resident
+// record; cap = voxel outside the search set (centroid +inf); cap + 1 = occupied voxel without an
+// LDS record (centroid -inf).  Sets L.RG.nspill = occupied voxels left without a record.
+__device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool) {
+  const Region r = L.RG;
+  const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
+  unsigned short *slot = reinterpret_cast<unsigned short *>(pool);
+  CellEntry *ent = reinterpret_cast<CellEntry *>(reinterpret_cast<char *>(pool) + ((r.rw * r.rh * 2 + 15) / 16) * 16);
+  const int ncell = r.rw * r.rh;
+  const int per = (ncell + kBlock - 1) / kBlock;
+  const int c0 = threadIdx.x * per, c1 = min(c0 + per, ncell);
+  auto wanted = [&](int lx, int ly) {
+    unsigned any = 0;
+    for (int dy = -2; dy <= 2; ++dy) {
+      const int yy = ly + dy;
+      if (yy < 0 || yy >= r.rh) continue;
+      const int xa = max(lx - 2, 0), xb = min(lx + 2, r.rw - 1);
+      for (int xx = xa; xx <= xb; ++xx) { const int bit = yy * r.rw + xx; any |= wmap[bit >> 5] >> (bit & 31); }
+    }
+    return (any & 1u) != 0u;
+  };
+  int mine = 0, skipped = 0;
+  unsigned keep = 0;                            // bit j: cell c0 + j gets a record (per <= 32)
+  for (int c = c0; c < c1; ++c) {
+    const int ly = c / r.rw, lx = c - ly * r.rw;
+    const float2 cc = M.cent[(size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2)];
+    if (cc.x < INFINITY) {                      // +inf marks voxels outside the search set
+      if (wanted(lx, ly)) { ++mine; keep |= 1u << (c - c0); } else ++skipped;
+    }
+  }
+  int incl = mine;                              // exclusive prefix of `mine` over the workgroup
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)(threadIdx.x & 63) >= o) incl += t; }
+  if ((threadIdx.x & 63) == 63) L.swave[threadIdx.x >> 6] = incl;
+  if (threadIdx.x == 0) L.sbox[0] = 0;
+  __syncthreads();
+  if (skipped) atomicAdd(&L.sbox[0], skipped);
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int w = 0; w < kWaves; ++w) { const int t = L.swave[w]; L.swave[w] = run; run += t; }
+    L.swave[kWaves] = run;
+  }
+  __syncthreads();
+  int next = L.swave[threadIdx.x >> 6] + incl - mine;
+  if (threadIdx.x == 0) {
+    CellEntry z; z.cent = make_float2(INFINITY, INFINITY); z.mx = z.my = z.i00 = z.i01 = z.i11 = 0.0;
+    ent[r.cap] = z;                             // voxels outside the search set
+    z.cent = make_float2(-INFINITY, -INFINITY);
+    ent[r.cap + 1] = z;                         // occupied voxels without an LDS record
+    L.RG.nspill = L.sbox[0] + (L.swave[kWaves] > r.cap ? L.swave[kWaves] - r.cap : 0);
+  }
+  for (int c = c0; c < c1; ++c) {
+    const int ly = c / r.rw, lx = c - ly * r.rw;
+    const size_t pg = (size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2);
+    const float2 cc = M.cent[pg];
+    unsigned sl = (unsigned)r.cap;
+    if (cc.x < INFINITY) {
+      sl = (unsigned)r.cap + 1u;
+      if ((keep >> (c - c0)) & 1u) {
+        if (next < r.cap) {
+          const double *rec = M.rec + pg * 8;
+          CellEntry E; E.cent = cc; E.mx = rec[0]; E.my = rec[1]; E.i00 = rec[2]; E.i01 = rec[3]; E.i11 = rec[4];
+          ent[next] = E;
+          sl = (unsigned)next;
+        }
+        ++next;
+      }
+    }
+    slot[c] = (unsigned short)sl;
+  }
+  __syncthreads();
+}
+
+// Owner: order every lane's own points by their in-radius voxel count at the first pose.
+// A wave walks its 64 lanes' k-th points together and runs the pair body max-over-lanes times, so
+// lanes should meet points of equal count at equal k.  Each lane counting-sorts its own points
+// (descending count, stable) in groups of 32 and writes them, lane-contiguous, to the scratch copy
+// the passes then read.  No cross-lane traffic; the order depends only on scan, map and first pose.
+template <bool SSE, bool INCL>
+__device__ __forceinline__ void order_points(const MapView &M, const Window &W, const Tf32 &T0,
+                                             const float2 *__restrict__ scan, int n, float2 *__restrict__ sp) {
+  for (int g0 = 0; g0 * kBlock + (int)threadIdx.x < n; g0 += 32) {
+    u64 k_lo = 0, k_hi = 0, hist = 0;    // 4-bit counts of 32 points; 6-bit histogram fields
+    int cnt = 0;
+#pragma nounroll
+    for (int jj = 0; jj < 32; ++jj) {
+      const int i = (g0 + jj) * kBlock + threadIdx.x;
+      if (i >= n) break;
+      const float2 pt = scan[i];
+      const u64 K = (u64)count_in_radius<SSE, INCL>(M, W, T0, pt.x, pt.y);
+      if (jj < 16) k_lo |= K << (4 * jj); else k_hi |= K << (4 * (jj - 16));
+      hist += 1ull << (6 * K);
+      ++cnt;
+    }
+    u64 starts = 0; unsigned run = 0;
+#pragma unroll
+    for (int kk = 9; kk >= 0; --kk) {     // descending count
+      starts |= (u64)run << (6 * kk);
+      run += (unsigned)((hist >> (6 * kk)) & 63ull);
+    }
+#pragma nounroll
+    for (int jj = 0; jj < cnt; ++jj) {
+      const unsigned K = (unsigned)(((jj < 16) ? (k_lo >> (4 * jj)) : (k_hi >> (4 * (jj - 16)))) & 15ull);
+      const unsigned pos = (unsigned)((starts >> (6 * K)) & 63ull);
+      starts += 1ull << (6 * K);
+      sp[(size_t)(g0 + (int)pos) * kBlock + threadIdx.x] = scan[(g0 + jj) * kBlock + threadIdx.x];
+    }
+  }
+}
+
+// Sum of 12 per-lane values over the 64 lanes of a wave in a fixed order, 86 instructions instead
+// of 12 x 18: a butterfly in which every exchange also halves the number of values a lane carries
+// (12 -> 6 -> 3 -> 2 -> 1), so only 24 cross-lane moves are needed.  The total of value j ends in
+// the lanes whose bits select j; those lanes store it to dst[j] (LDS).
+__device__ __forceinline__ void wave_reduce12(const double (&a)[12], int lane, double *__restrict__ dst) {
+  const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+  double k[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {                       // keep values 0..5 (b5 = 0) or 6..11 (b5 = 1)
+    const double keep = b5 ? a[i + 6] : a[i], send = b5 ? a[i] : a[i + 6];
+    k[i] = keep + __shfl_xor(send, 32);
+  }
+  double m[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {                       // keep 0..2 or 3..5 of those
+    const double keep = b4 ? k[i + 3] : k[i], send = b4 ? k[i] : k[i + 3];
+    m[i] = keep + __shfl_xor(send, 16);
+  }
+  const double p0 = (b3 ? m[1] : m[0]) + __shfl_xor(b3 ? m[0] : m[1], 8);   // value 0 or 1 of the triple
+  const double p1 = m[2] + __shfl_xor(m[2], 8);                            // value 2
+  double r = (b2 ? p1 : p0) + __shfl_xor(b2 ? p0 : p1, 4);
+  r += __shfl_xor(r, 2);
+  r += __shfl_xor(r, 1);
+  const int idx = (b5 ? 6 : 0) + (b4 ? 3 : 0) + (b2 ? 2 : (b3 ? 1 : 0));
+  if ((lane & 3) == 0 && !(b2 && b3)) dst[idx] = r;
+}
+
+// Units of a pass: unit u = (virtual wave w = u % kWaves, run q = u / kWaves) is the lane set
+// {w*64 .. w*64+63} walking the q-th run of its points i = w*64 + lane + k*kBlock,
+// k in [q*run, (q+1)*run), of the (ordered) scan.  Any physical wave of any workgroup can compute
+// a unit; its sums are reduced over the 64 lanes in a fixed order, and a pass total is the sum of
+// the kUnits unit totals in unit order -- the same arithmetic whether the owner computed all units
+// itself or helpers computed some.
+// This routine computes the consecutive runs [q0, q1) of virtual wave w in ONE walk over k (the
+// point prefetch keeps running across run boundaries) and leaves the 12 sums of run q at
+// dst[(q - q0) * dst_stride .. +12) (LDS).
+template <bool SSE, bool INCL>
+__device__ __forceinline__ void unit_sums(const MapView &M, const Window &W, const double *__restrict__ etab,
+                                          const PassPose &pp, const float2 *__restrict__ pts, int n, int w,
+                                          int q0, int q1, double *__restrict__ dst, int dst_stride) {
+  const int lane = threadIdx.x & 63, last = n - 1;
+  const int per_lane = (n + kBlock - 1) / kBlock;          // points of the longest lane
+  const int run = (per_lane + kSub - 1) / kSub;
+  const int kbeg = min(per_lane, q0 * run), kend = min(per_lane, q1 * run);
+  const int base = w * 64 + lane;
+  if (pp.kind == 0) {
+    Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+    float2 p0 = pts[min(base + kbeg * kBlock, last)], p1 = pts[min(base + (kbeg + 1) * kBlock, last)];
+    int q = q0, kb = min(per_lane, (q0 + 1) * run);        // end of the current run
+#pragma nounroll
+    for (int k = kbeg; k < kend; ++k) {
+      const float2 p2 = pts[min(base + (k + 2) * kBlock, last)];
+      if (base + k * kBlock >= n) p0.x = NAN;              // past the end: contributes nothing
+      eval_point<SSE, INCL>(M, W, etab, pp.T, p0.x, p0.y, pp.cj, pp.sj, pp.ch, pp.sh, A);
+      p0 = p1; p1 = p2;
+      if (k + 1 == kb) {                                   // run q complete (uniform across the wave)
+        const double a[12] = {A.e, A.g0, A.g1, A.g2, A.hxx, A.hxy, A.hxt, A.hyy, A.hyt, A.htt, (double)A.pairs, 0.0};
+        wave_reduce12(a, lane, dst + (q - q0) * dst_stride);
+        A = Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+        ++q; kb = min(per_lane, (q + 1) * run);
+      }
+    }
+    for (; q < q1; ++q) {                                  // empty runs (short scans)
+      if (lane < 12) dst[(q - q0) * dst_stride + lane] = 0.0;
+    }
+  } else {
+    for (int q = q0; q < q1; ++q) {
+      const int k0 = min(per_lane, q * run), k1 = min(per_lane, (q + 1) * run);
+      double fsum = 0.0, fcnt = 0.0;
+      for (int k = k0; k < k1; ++k) {
+        const int i = base + k * kBlock;
+        if (i >= n) break;
+        const float2 pt = pts[i];
+        float qx, qy;
+        tf_apply_t<SSE>(pp.T, pt.x, pt.y, qx, qy);
+        if (!finite2(qx, qy)) continue;
+        const float best = nearest_sq(M, qx, qy);
+        if (best < INFINITY) { fsum += (double)best; fcnt += 1.0; }
+      }
+      fsum = wave_sum(fsum); fcnt = wave_sum(fcnt);
+      if (lane == 0) { dst[(q - q0) * dst_stride] = fsum; dst[(q - q0) * dst_stride + 1] = fcnt; }
+    }
+  }
+}
+
+// Bound on every spin: looked at once per 64 polls (the abort word is one line shared by the chip).
+__device__ __forceinline__ bool watchdog(WsHeader *hdr, u64 t_start, unsigned &polls) {
+  if ((++polls & 63u) != 0u) return false;
+  if (ld32(&hdr->abort)) return true;
+  if (wall_clock64() - t_start > kWatchTicks) { st32(&hdr->abort, 1u); return true; }
+  return false;
+}
+
+__device__ __forceinline__ u64 wave_bcast64(u64 v) {   // lane 0's value to the whole wave
+  const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+  return ((u64)hi << 32) | lo;
+}
+
 template <bool SSE, bool INCL>
 __global__ void __launch_bounds__(kBlock)
 ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
@@ -723,212 +1102,179 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
                  const double *__restrict__ inits, ndt_result *__restrict__ results,
                  double *__restrict__ trace, int trace_cap, int *__restrict__ trace_rows,
                  float2 *__restrict__ sorted /* scratch, same offsets as scans; may be null */,
-                 unsigned long long *__restrict__ prof /* diagnostic: 4 x ticks per scan */) {
-  __shared__ AlignState S;
-  __shared__ double sred[(kWaves + 1) * kAcc];
-  __shared__ Region RG;
-  __shared__ int sbox[4];
-  __shared__ int swave[kWaves + 1];
-  __shared__ double etab[64];
+                 unsigned char *__restrict__ ws /* WsHeader, ScanCtl[B], unit totals[B][kUnits][12], marked-cell bitmaps[B][kRegionCells/32] */,
+                 int allow_helpers /* 0: none; else max helper workgroups per scan */,
+                 unsigned long long *__restrict__ prof /* diagnostic: 4 words per scan */) {
+  __shared__ Lds L;
   __shared__ uint4 pool[kPoolBytes / 16];
-  if (threadIdx.x < 64) etab[threadIdx.x] = c_exp2_tab[threadIdx.x];
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
-    const unsigned long long o1 = shared_scan ? offsets[1] : offsets[b + 1];
+  WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
+  ScanCtl *ctl = reinterpret_cast<ScanCtl *>(ws + sizeof(WsHeader));
+  u64 *utot = reinterpret_cast<u64 *>(ws + sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl));
+  unsigned *wantmap = reinterpret_cast<unsigned *>(ws + sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl) +
+                                                  (size_t)B * kUnits * 12 * sizeof(double));
+  const u64 t_start = wall_clock64();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 64) L.etab[threadIdx.x] = c_exp2_tab[threadIdx.x];
+  bool aborted = false;
+
+  // =========================== owner of scans blockIdx.x, + gridDim.x, ... ===========================
+  for (int b = blockIdx.x; b < B && !aborted; b += gridDim.x) {
+    const u64 o0 = shared_scan ? offsets[0] : offsets[b];
+    const u64 o1 = shared_scan ? offsets[1] : offsets[b + 1];
     const int n = (int)(o1 - o0);
     const float2 *scan = reinterpret_cast<const float2 *>(scans) + o0;
     double *tr = trace ? trace + (size_t)b * trace_cap * 8 : nullptr;
+    ScanCtl *C = ctl + b;
+    u64 *mytot = utot + (size_t)b * kUnits * 12;
     __syncthreads();
     if (threadIdx.x == 0) {
-      init_state(S, P, inits + 3 * (size_t)b, (double)n);
+      init_state(L.S, P, inits + 3 * (size_t)b, (double)n);
       if (trace_rows) trace_rows[b] = 0;
-      if (n <= 0) { S.phase = PH_DONE; S.converged = 0; }
-      sbox[0] = INT_MAX; sbox[1] = INT_MAX; sbox[2] = INT_MIN; sbox[3] = INT_MIN;
+      if (n <= 0) { L.S.phase = PH_DONE; L.S.converged = 0; }
     }
     __syncthreads();
-    // ---- stage the part of the map this scan can reach in LDS ----
-    {
-      const Tf32 T0 = S.T;
-      int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
-      for (int i = threadIdx.x; i < n; i += kBlock) {
-        const float2 pt = scan[i];
-        float xt, yt;
-        tf_apply_t<SSE>(T0, pt.x, pt.y, xt, yt);
-        if (!finite2(xt, yt)) continue;
-        const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
-        const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
-        const int ix = (int)fx - M.min_bx, iy = (int)fy - M.min_by;
-        mnx = ix < mnx ? ix : mnx; mxx = ix > mxx ? ix : mxx;
-        mny = iy < mny ? iy : mny; mxy = iy > mxy ? iy : mxy;
-      }
-      mnx = wave_min_i(mnx); mny = wave_min_i(mny); mxx = wave_max_i(mxx); mxy = wave_max_i(mxy);
-      if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
-        atomicMin(&sbox[0], mnx); atomicMin(&sbox[1], mny); atomicMax(&sbox[2], mxx); atomicMax(&sbox[3], mxy);
-      }
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        Region r = {0, 0, 0, 0, 0, 0};
-        if (sbox[0] <= sbox[2]) {
-          // clip the bbox to the padded map grid, add the slack, then fit the slot-table budget
-          // around the bbox centre
-          long long x0 = (long long)sbox[0] - kRegionMargin, x1 = (long long)sbox[2] + kRegionMargin;
-          long long y0 = (long long)sbox[1] - kRegionMargin, y1 = (long long)sbox[3] + kRegionMargin;
-          x0 = x0 < -2 ? -2 : x0; y0 = y0 < -2 ? -2 : y0;
-          x1 = x1 > M.div_x + 1 ? M.div_x + 1 : x1; y1 = y1 > M.div_y + 1 ? M.div_y + 1 : y1;
-          long long w = x1 - x0 + 1, h = y1 - y0 + 1;
-          if (w > 0 && h > 0) {
-            if (w * h > kRegionCells) {
-              long long w2 = w > 128 ? 128 : w;
-              long long h2 = kRegionCells / w2; if (h2 > h) h2 = h;
-              x0 += (w - w2) / 2; y0 += (h - h2) / 2; w = w2; h = h2;
-            }
-            r.x0 = (int)x0; r.y0 = (int)y0; r.rw = (int)w; r.rh = (int)h;
-          }
-        }
-        const int slot_bytes = ((r.rw * r.rh * 2 + 15) / 16) * 16;
-        int cap = (kPoolBytes - slot_bytes) / (int)sizeof(CellEntry) - 1;   // last one = sentinel
-        r.cap = cap > 0xFFFF ? 0xFFFF : cap;
-        RG = r;
-      }
-      __syncthreads();
-      const Region r = RG;
-      unsigned short *slot = reinterpret_cast<unsigned short *>(pool);
-      CellEntry *ent = reinterpret_cast<CellEntry *>(reinterpret_cast<char *>(pool) +
-                                                     ((r.rw * r.rh * 2 + 15) / 16) * 16);
-      // each lane owns a contiguous run of window cells: slots are numbered in row-major order,
-      // so which records spill (if any) does not depend on timing
-      const int ncell = r.rw * r.rh;
-      const int per = (ncell + kBlock - 1) / kBlock;
-      const int c0 = threadIdx.x * per, c1 = min(c0 + per, ncell);
-      int mine = 0;
-      for (int c = c0; c < c1; ++c) {
-        const int ly = c / r.rw, lx = c - ly * r.rw;
-        const float2 cc = M.cent[(size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2)];
-        mine += (cc.x < INFINITY) ? 1 : 0;      // +inf marks voxels outside the search set
-      }
-      // exclusive prefix of `mine` over the workgroup
-      int incl = mine;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)(threadIdx.x & 63) >= o) incl += t; }
-      if ((threadIdx.x & 63) == 63) swave[threadIdx.x >> 6] = incl;
-      __syncthreads();
-      if (threadIdx.x == 0) { int run = 0; for (int w = 0; w < kWaves; ++w) { const int t = swave[w]; swave[w] = run; run += t; } swave[kWaves] = run; }
-      __syncthreads();
-      int next = swave[threadIdx.x >> 6] + incl - mine;
-      if (threadIdx.x == 0) {
-        CellEntry z; z.cent = make_float2(INFINITY, INFINITY); z.mx = z.my = z.i00 = z.i01 = z.i11 = 0.0;
-        ent[r.cap] = z;                          // sentinel record of the voxels outside the search set
-        RG.nspill = swave[kWaves] > r.cap ? swave[kWaves] - r.cap : 0;
-      }
-      for (int c = c0; c < c1; ++c) {
-        const int ly = c / r.rw, lx = c - ly * r.rw;
-        const size_t pg = (size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2);
-        const float2 cc = M.cent[pg];
-        unsigned sl = (unsigned)r.cap;
-        if (cc.x < INFINITY) {
-          if (next < r.cap) {
-            const double *rec = M.rec + pg * 8;
-            CellEntry E; E.cent = cc; E.mx = rec[0]; E.my = rec[1]; E.i00 = rec[2]; E.i01 = rec[3]; E.i11 = rec[4];
-            ent[next] = E;
-            sl = (unsigned)next;
-          }
-          ++next;
-        }
-        slot[c] = (unsigned short)sl;
-      }
-      __syncthreads();
-    }
-    Window W;
-    W.R = RG;
-    W.slot = reinterpret_cast<const unsigned short *>(pool);
-    W.ent = reinterpret_cast<const CellEntry *>(reinterpret_cast<const char *>(pool) +
-                                                ((W.R.rw * W.R.rh * 2 + 15) / 16) * 16);
-    // ---- order every lane's own points by their in-radius voxel count at the first pose ----
-    // A wave walks its 64 lanes' k-th points together and runs the pair body max-over-lanes times,
-    // so lanes should meet points of equal count at equal k.  Each lane counting-sorts its own
-    // points (descending count, stable) in groups of 32 and writes them, lane-contiguous, to the
-    // scratch copy the passes then read.  No cross-lane traffic; the order depends only on the
-    // scan, the map and the initial pose.
     const float2 *pts = scan;
-    if (sorted && !shared_scan) {
-      float2 *sp = sorted + o0;
-      const Tf32 T0 = S.T;
-      for (int g0 = 0; g0 * kBlock + (int)threadIdx.x < n; g0 += 32) {
-        unsigned long long k_lo = 0, k_hi = 0, hist = 0;   // 4-bit counts of 32 points; 6-bit histogram fields
-        int cnt = 0;
-#pragma nounroll
-        for (int jj = 0; jj < 32; ++jj) {
-          const int i = (g0 + jj) * kBlock + threadIdx.x;
-          if (i >= n) break;
-          const float2 pt = scan[i];
-          const unsigned long long K = (unsigned long long)count_in_radius<SSE, INCL>(M, W, T0, pt.x, pt.y);
-          if (jj < 16) k_lo |= K << (4 * jj); else k_hi |= K << (4 * (jj - 16));
-          hist += 1ull << (6 * K);
-          ++cnt;
+    if (n > 0) {
+      compute_region<SSE>(M, L.S.T, scan, n, L);
+      mark_wanted<SSE>(M, L.S.T, scan, n, L);
+      if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
+        const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
+        unsigned *gw = wantmap + (size_t)b * (kRegionCells / 32);
+        for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) gw[i] = wmap[i];
+      }
+      fill_window(M, L, pool);
+      const Window W0 = window_of(L.RG, pool);
+      if (sorted && !shared_scan) {
+        float2 *sp = sorted + o0;
+        order_points<SSE, INCL>(M, W0, L.S.T, scan, n, sp);
+        pts = sp;
+      }
+      if (allow_helpers) {
+        // publish geometry + ordered copy: plain stores, drained by every wave, then one agent release
+        if (threadIdx.x == 0) {
+          const Region r = L.RG;
+          C->region[0] = r.x0; C->region[1] = r.y0; C->region[2] = r.rw; C->region[3] = r.rh;
+          C->region[4] = r.cap; C->region[5] = r.nspill;
         }
-        unsigned long long starts = 0; unsigned run = 0;
-#pragma unroll
-        for (int kk = 9; kk >= 0; --kk) {                   // descending count
-          starts |= (unsigned long long)run << (6 * kk);
-          run += (unsigned)((hist >> (6 * kk)) & 63ull);
-        }
-#pragma nounroll
-        for (int jj = 0; jj < cnt; ++jj) {
-          const unsigned K = (unsigned)(((jj < 16) ? (k_lo >> (4 * jj)) : (k_hi >> (4 * (jj - 16)))) & 15ull);
-          const unsigned pos = (unsigned)((starts >> (6 * K)) & 63ull);
-          starts += 1ull << (6 * K);
-          sp[(size_t)(g0 + (int)pos) * kBlock + threadIdx.x] = scan[(g0 + jj) * kBlock + threadIdx.x];
+        drain_vmem();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          drain_vmem();
+          st64(&C->ticket, ((u64)1 << 32) | (u64)kUnits);     // epoch 1: open for joining, no unit on offer
         }
       }
-      pts = sp;
-      __syncthreads();
     }
-    unsigned long long t_eval = 0, t_adv = 0, t0 = 0, t1 = 0;
-    // ---- optimisation loop: every iteration is one derivative pass (HOT LOOP A+B fused) ----
-    for (;;) {
-      if (S.phase == PH_DONE) break;
-      if (prof) t0 = wall_clock64();
-      const Tf32 T = S.T;
-      const double cj = S.cj, sj = S.sj, ch = S.ch, sh = S.sh;
-      Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
-      // the lane's points come from L2 (coalesced, two loads kept in flight); all map data from LDS
+    const Window W = window_of(L.RG, pool);
+    unsigned epoch = 1;
+    u64 t_eval = 0, t_adv = 0, tt0 = 0, tt1 = 0, t_wait = 0, t_first_shared = 0, t_fit = 0;
+    const u64 t_scan0 = wall_clock64() - t_start;
+    unsigned n_shared = 0, n_helped = 0;
+    bool fitness_done = false;
+    // ---- passes: derivative passes until the optimiser stops, then one fitness pass ----
+    while (n > 0 && !fitness_done) {
+      if (prof) tt0 = wall_clock64();
+      const bool fit_pass = (L.S.phase == PH_DONE);
+      if (threadIdx.x == 0) {
+        L.PP.T = L.S.T; L.PP.cj = L.S.cj; L.PP.sj = L.S.sj; L.PP.ch = L.S.ch; L.PP.sh = L.S.sh;
+        L.PP.kind = fit_pass ? 1 : 0;
+        const int h = allow_helpers >= 1000 ? 1 : (allow_helpers ? (int)rd32_fresh(&C->helpers) : 0);   // >= 1000: diagnostic, force shared passes
+        if (allow_helpers) st32(&C->passes, (u32)L.S.evals);
+        // the fitness pass is the longest of a match and runs once: always open it to helpers, also to
+        // those that attach while it is running
+        const int hh = (h == 0 && fit_pass && allow_helpers && allow_helpers < 1000) ? 1 : h;
+        L.sflag[0] = hh;
+        L.own_mask = 0u;
+        if (hh > 0) {                          // open an epoch: pose block, then the ticket
+          const PassPose pp = L.PP;
+          st64(&C->pose[0], ((u64)__float_as_uint(pp.T.s) << 32) | (u64)__float_as_uint(pp.T.c));
+          st64(&C->pose[1], ((u64)__float_as_uint(pp.T.ty) << 32) | (u64)__float_as_uint(pp.T.tx));
+          st64(&C->pose[2], (u64)__double_as_longlong(pp.cj)); st64(&C->pose[3], (u64)__double_as_longlong(pp.sj));
+          st64(&C->pose[4], (u64)__double_as_longlong(pp.ch)); st64(&C->pose[5], (u64)__double_as_longlong(pp.sh));
+          st64(&C->kind, (u64)pp.kind);
+          st32(&C->arrive, 0u);
+          drain_vmem();
+          st64(&C->ticket, (u64)(epoch + 1) << 32);
+        }
+      }
+      __syncthreads();
+      const int nhelp = L.sflag[0];
+      const PassPose pp = L.PP;
+      if (nhelp <= 0) {
+        // solo pass: physical wave w computes its own units (w, 0..kSub-1)
+        unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, wave, 0, kSub, L.wpart + wave * 12, kWaves * 12);
+        if (threadIdx.x == 0) L.own_mask = ~0ull;
+      } else {
+        // shared pass: this workgroup's waves and the helpers' waves claim units from the ticket.
+        // Waves beyond the owner's fair share hold back a moment so that helpers get theirs.
+        ++epoch;
+        const int quota = (kWaves + nhelp) / (nhelp + 1);     // owner waves that start at once
+#ifndef NDT_NO_QUOTA_DELAY
+        if (wave >= quota) { const u64 w0 = wall_clock64(); while (wall_clock64() - w0 < 500) __builtin_amdgcn_s_sleep(16); }
+#endif
+        // (a counted loop on purpose: hipcc / ROCm 7.2 miscompiles `for (;;)` + break around
+        // cross-lane work followed by a lane-0 LDS atomic -- tools/repro/ticket2.hip)
+        for (int claims = 0; claims <= kUnits; ++claims) {
+          u64 v = 0;
+          if (lane == 0) v = __hip_atomic_fetch_add(&C->ticket, 1ull, NDT_RLX, NDT_AGENT);
+          v = wave_bcast64(v);
+          const u32 idx = (u32)v;
+          if (idx >= (u32)kUnits) break;
+          unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, (int)(idx % kWaves), (int)(idx / kWaves), (int)(idx / kWaves) + 1,
+                               L.wpart + idx * 12, 0);
+          if (lane == 0) atomicOr(&L.own_mask, 1ull << idx);
+        }
+        __syncthreads();
+        // wait for the units the helpers claimed (running waves are computing them)
+        if (threadIdx.x == 0) {
+          const u32 need = (u32)(kUnits - __builtin_popcountll(L.own_mask));
+          int bad = 0; unsigned polls = 0;
+          const u64 w0 = wall_clock64();
+          while (ld32(&C->arrive) < need) {
+            if (watchdog(hdr, t_start, polls)) { bad = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+          }
+          t_wait += wall_clock64() - w0;
+          if (n_shared == 0) t_first_shared = w0 - t_start;
+          n_shared += 1; n_helped += need;
+          L.sflag[2] = bad;
+        }
+        __syncthreads();
+        if (L.sflag[2]) { aborted = true; break; }
+      }
+      __syncthreads();
+      // pass total = sum of the unit totals in unit order (own units from LDS, helpers' from HBM)
       {
-        const int last = n - 1;
-        int i = threadIdx.x;
-        float2 p0 = pts[min(i, last)], p1 = pts[min(i + kBlock, last)];
-#pragma nounroll
-        for (; i < n; i += kBlock) {
-          const float2 p2 = pts[min(i + 2 * kBlock, last)];
-          eval_point<SSE, INCL>(M, W, etab, T, p0.x, p0.y, cj, sj, ch, sh, A);
-          p0 = p1; p1 = p2;
+        const unsigned long long mine = L.own_mask;
+        if (mine != ~0ull && threadIdx.x < kUnits * 12) {     // helpers' totals: one load per lane, in flight together
+          const int v = threadIdx.x / 12;
+          if (!((mine >> v) & 1ull)) L.wpart[threadIdx.x] = __longlong_as_double((long long)ld64(&mytot[threadIdx.x]));
+        }
+        __syncthreads();
+        if (threadIdx.x < 12) {
+          double s = 0.0;
+          for (int v = 0; v < kUnits; ++v) s += L.wpart[v * 12 + threadIdx.x];
+          L.tot[threadIdx.x] = s;
         }
       }
-      block_reduce_acc(A, sred);
-      if (prof) { t1 = wall_clock64(); t_eval += t1 - t0; }
-      if (threadIdx.x == 0)
-        advance(S, P, M, sred + kWaves * kAcc, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
       __syncthreads();
-      if (prof) t_adv += wall_clock64() - t1;
+      if (prof) { tt1 = wall_clock64(); t_eval += tt1 - tt0; if (fit_pass) t_fit = tt1 - tt0; }
+      if (!fit_pass) {
+        if (threadIdx.x == 0) advance(L.S, P, M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
+      } else {
+        fitness_done = true;
+      }
+      __syncthreads();
+      if (prof) t_adv += wall_clock64() - tt1;
     }
-    // ---- epilogue: fitness score at the final float32 transform (HOT LOOP C) ----
-    if (prof) t0 = wall_clock64();
-    const Tf32 T = S.T;
-    double fsum = 0.0, fcnt = 0.0;
-    auto fit = [&](float x, float y) {
-      float qx, qy;
-      tf_apply_t<SSE>(T, x, y, qx, qy);
-      if (!finite2(qx, qy)) return;
-      float best = nearest_sq(M, qx, qy);
-      if (best < INFINITY) { fsum += (double)best; fcnt += 1.0; }
-    };
-    for (int i = threadIdx.x; i < n; i += kBlock) { float2 pt = pts[i]; fit(pt.x, pt.y); }
-    block_reduce2(fsum, fcnt, sred);
+    // ---- result record; close the scan ----
     if (threadIdx.x == 0) {
-      const double fs[2] = {sred[kWaves * 2], sred[kWaves * 2 + 1]};
+      const AlignState &S = L.S;
+      const Tf32 T = S.T;
       ndt_result R_;
       R_.pose[0] = (double)T.tx; R_.pose[1] = (double)T.ty; R_.pose[2] = yaw_from_T(T.c, T.s);
       R_.T00 = T.c; R_.T10 = T.s; R_.T03 = T.tx; R_.T13 = T.ty;
-      R_.fitness = fs[1] > 0 ? fs[0] / fs[1] : DBL_MAX;
+      R_.fitness = (fitness_done && L.tot[1] > 0) ? L.tot[0] / L.tot[1] : DBL_MAX;
       R_.score = S.score;
       R_.trans_prob = n > 0 ? S.score / (double)n : 0.0;
       R_.H[0] = S.H[0]; R_.H[1] = S.H[1]; R_.H[2] = S.H[2];
@@ -938,13 +1284,133 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       R_.iters = S.iters; R_.evals = S.evals;
       R_.ref_evals = S.ref_evals + 1;       // + the getHessian pass (src/PoseEstimator.cpp:56)
       R_.converged = S.converged;
-      R_.status = n > 0 ? NDT_OK : NDT_E_ARG;
+      R_.status = aborted ? NDT_E_HIP : (n > 0 ? NDT_OK : NDT_E_ARG);
       R_.pad_ = 0;
       R_.kbar = (S.evals > 0 && n > 0) ? S.pairs / ((double)S.evals * (double)n) : 0.0;
       results[b] = R_;
+      if (allow_helpers) {
+        st64(&C->ticket, (u64)kEpochDone << 32);
+        __hip_atomic_fetch_add(&hdr->done, 1u, NDT_RLX, NDT_AGENT);
+      }
       if (prof) {
-        prof[4 * b + 0] = t_eval; prof[4 * b + 1] = t_adv; prof[4 * b + 2] = wall_clock64() - t0;
-        prof[4 * b + 3] = (unsigned long long)S.evals;
+        prof[4 * b + 0] = t_eval; prof[4 * b + 1] = t_adv | (t_fit << 32) | ((u64)(L.RG.nspill > 0) << 63); prof[4 * b + 2] = (t_first_shared << 32) | (t_scan0 & 0xFFFFFFFFull);
+        prof[4 * b + 3] = (unsigned long long)S.evals | ((u64)n_shared << 16) | ((u64)n_helped << 32);
+      }
+    }
+  }
+
+  // ============================================ helper ============================================
+  if (!allow_helpers || aborted || allow_helpers >= 1000) return;
+  u64 idle_ticks = 400;
+  for (unsigned rounds = 0; rounds < 0x40000000u; ++rounds) {
+    // ---- find an unfinished scan that still has room for a helper ----
+    __syncthreads();
+    if (threadIdx.x == 0) { L.sflag[0] = INT_MAX; L.sflag[3] = 0; }
+    __syncthreads();
+    const int start = (int)((blockIdx.x * 97u) % (unsigned)B);
+    for (int k = threadIdx.x; k < B; k += kBlock) {
+      int b = start + k; if (b >= B) b -= B;
+      const u32 ep = (u32)(rd64_fresh(&ctl[b].ticket) >> 32);
+      if (ep == 0u || ep == kEpochDone) continue;
+      const u32 h = rd32_fresh(&ctl[b].helpers);
+      if (h >= (u32)allow_helpers) continue;
+      // a scan that already needed many passes will likely need many more: most passes first,
+      // each attached helper counting like 4 passes fewer; then nearest
+      const int score = (int)min(ld32(&ctl[b].passes), 200u) - 4 * (int)h;       // -28 .. 200
+      atomicMin(&L.sflag[0], (int)(((u32)(256 - score) << 20) | (u32)k));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int code = -1;                                       // -1: nothing joinable right now
+      unsigned polls = 63;
+      if (ld32(&hdr->done) >= (u32)B || watchdog(hdr, t_start, polls)) code = -2;   // -2: leave
+      else if (L.sflag[0] != INT_MAX) {
+        int b = start + (L.sflag[0] & 0xFFFFF); if (b >= B) b -= B;
+        const u32 h = __hip_atomic_fetch_add(&ctl[b].helpers, 1u, NDT_RLX, NDT_AGENT);
+        if (h >= (u32)allow_helpers) {
+          __hip_atomic_fetch_sub(&ctl[b].helpers, 1u, NDT_RLX, NDT_AGENT);   // lost the race: look again
+        } else {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // geometry + ordered copy of the owner
+          drain_vmem();
+          if (prof && h == 0) prof[4 * B + 2 * b] = wall_clock64() - t_start;
+          code = b;
+        }
+      }
+      L.sflag[3] = code;
+      if (code == -1) {                                    // back off: 4 us, doubling up to ~64 us
+        const u64 t0 = wall_clock64();
+        while (wall_clock64() - t0 < idle_ticks) __builtin_amdgcn_s_sleep(64);
+        if (idle_ticks < 6400) idle_ticks *= 2;
+      } else {
+        idle_ticks = 400;
+      }
+    }
+    __syncthreads();
+    const int vb = L.sflag[3];
+    if (vb == -2) break;
+    if (vb < 0) continue;
+    // ---- attached to scan vb: stage its window, then every wave claims units until the scan is done ----
+    ScanCtl *C = ctl + vb;
+    const u64 o0 = shared_scan ? offsets[0] : offsets[vb];
+    const u64 o1 = shared_scan ? offsets[1] : offsets[vb + 1];
+    const int n = (int)(o1 - o0);
+    const float2 *pts = (sorted && !shared_scan) ? (sorted + o0) : (reinterpret_cast<const float2 *>(scans) + o0);
+    if (threadIdx.x == 0) {
+      Region r; r.x0 = C->region[0]; r.y0 = C->region[1]; r.rw = C->region[2]; r.rh = C->region[3];
+      r.cap = C->region[4]; r.nspill = C->region[5];
+      L.RG = r;
+    }
+    {
+      unsigned *wmap = reinterpret_cast<unsigned *>(L.wpart);
+      const unsigned *gw = wantmap + (size_t)vb * (kRegionCells / 32);
+      for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) wmap[i] = gw[i];
+    }
+    __syncthreads();
+    fill_window(M, L, pool);
+    const Window W = window_of(L.RG, pool);
+    if (prof && threadIdx.x == 0 && prof[4 * B + 2 * vb + 1] == 0) prof[4 * B + 2 * vb + 1] = wall_clock64() - t_start;
+    u64 *vtot = utot + (size_t)vb * kUnits * 12;
+    {
+      unsigned my_ep = 0, polls = 0;
+      PassPose pp; pp.kind = 0; pp.cj = pp.sj = pp.ch = pp.sh = 0.0; pp.T.c = pp.T.s = pp.T.tx = pp.T.ty = 0.f;
+      for (unsigned turns = 0; turns < 0x40000000u; ++turns) {       // counted, see the owner's claim loop
+        u64 v = 0;
+        if (lane == 0) v = __hip_atomic_fetch_add(&C->ticket, 1ull, NDT_RLX, NDT_AGENT);
+        v = wave_bcast64(v);
+        const u32 ep = (u32)(v >> 32), idx = (u32)v;
+        if (ep == kEpochDone) break;
+        if (idx >= (u32)kUnits) {
+          // nothing on offer: wait for the next epoch (or the end of the scan)
+          int bad = 0;
+          if (lane == 0) {
+            while ((u32)(ld64(&C->ticket) >> 32) == ep) {
+              if (watchdog(hdr, t_start, polls)) { bad = 1; break; }
+              __builtin_amdgcn_s_sleep(48);
+            }
+          }
+          bad = __builtin_amdgcn_readfirstlane(bad);
+          if (bad) break;
+          continue;
+        }
+        if (ep != my_ep) {                                   // first unit of a new epoch: its pose block
+          u64 w = 0;
+          if (lane < 7) w = ld64(lane < 6 ? &C->pose[lane] : &C->kind);
+          const u64 w0 = __shfl(w, 0), w1 = __shfl(w, 1), w2 = __shfl(w, 2), w3 = __shfl(w, 3), w4 = __shfl(w, 4),
+                    w5 = __shfl(w, 5), w6 = __shfl(w, 6);
+          pp.T.c = __uint_as_float((u32)w0); pp.T.s = __uint_as_float((u32)(w0 >> 32));
+          pp.T.tx = __uint_as_float((u32)w1); pp.T.ty = __uint_as_float((u32)(w1 >> 32));
+          pp.cj = __longlong_as_double((long long)w2); pp.sj = __longlong_as_double((long long)w3);
+          pp.ch = __longlong_as_double((long long)w4); pp.sh = __longlong_as_double((long long)w5);
+          pp.kind = (int)w6;
+          my_ep = ep;
+        }
+        double *wt = L.wtmp + wave * 12;
+        unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, (int)(idx % kWaves), (int)(idx / kWaves), (int)(idx / kWaves) + 1, wt, 0);
+        if (lane < 12) st64(&vtot[idx * 12 + lane], (u64)__double_as_longlong(wt[lane]));
+        drain_vmem();                                        // the whole wave: its stores have landed
+        if (lane == 0) {
+          __hip_atomic_fetch_add(&C->arrive, 1u, NDT_RLX, NDT_AGENT);
+        }
       }
     }
   }
@@ -975,7 +1441,7 @@ ndt_eval_kernel(MapView M, double snap, const float *__restrict__ scan, size_t s
     float2 pt = load_pt(scan, stride, i);
     eval_point<SSE, INCL>(M, W, etab, T, pt.x, pt.y, cj, sj, cj, sj, A);
   }
-  block_reduce_acc(A, sred);
+  block_reduce_acc(A, sred, sred + 4 * kAcc);
   if (threadIdx.x < kAcc) partial[blockIdx.x * kAcc + threadIdx.x] = sred[4 * kAcc + threadIdx.x];
 }
 
@@ -992,7 +1458,7 @@ ndt_fitness_kernel(MapView M, const float *__restrict__ scan, size_t stride, int
     float best = nearest_sq(M, qx, qy);
     if (best < INFINITY) { fsum += (double)best; fcnt += 1.0; }
   }
-  block_reduce2(fsum, fcnt, sred);
+  block_reduce2(fsum, fcnt, sred, sred + 4 * 2);
   if (threadIdx.x < 2) partial[blockIdx.x * 2 + threadIdx.x] = sred[4 * 2 + threadIdx.x];
 }
 
@@ -1286,6 +1752,9 @@ struct ndt_ctx {
   void *d_trace = nullptr; size_t d_trace_cap = 0;
   void *d_rows = nullptr; size_t d_rows_cap = 0;
   void *d_sorted = nullptr; size_t d_sorted_cap = 0;   // per-lane ordered copy of the scans
+  void *d_ws = nullptr; size_t d_ws_cap = 0;           // WsHeader + ScanCtl[B] + chunk totals
+  int num_cus = 0;
+  int helpers = 1;                                     // NDT_NO_HELPERS=1 disables work sharing (diagnostic)
 };
 
 struct ndt_map {
@@ -1367,20 +1836,32 @@ int grid_for(size_t n, int block, int cap = 2048) {
   return (int)g;
 }
 
-void launch_align(const ndt_map *map, hipStream_t st, const float *scans, const unsigned long long *offsets,
-                  int B, int shared_scan, const double *inits, ndt_result *out, double *trace, int trace_cap,
-                  int *trace_rows, float2 *sorted, unsigned long long *prof) {
+int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *scans,
+                 const unsigned long long *offsets, int B, int shared_scan, const double *inits, ndt_result *out,
+                 double *trace, int trace_cap, int *trace_rows, float2 *sorted, unsigned long long *prof) {
   const bool sse = map->prm.transform_sse != 0, incl = map->prm.radius_inclusive != 0;
   const MapView &V = map->view;
   const OptParams O = opt_of(map->prm);
+  // workspace: header + one control line per scan (zeroed every launch) + chunk totals
+  const size_t zero_bytes = sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl);
+  const size_t ws_bytes = zero_bytes + (size_t)B * kUnits * 12 * sizeof(double) + (size_t)B * (kRegionCells / 8);
+  int rc = ensure(ctx, &ctx->d_ws, &ctx->d_ws_cap, ws_bytes);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_ws, 0, zero_bytes, st));
+  unsigned char *ws = (unsigned char *)ctx->d_ws;
+  const int helpers = ctx->helpers;
+  // one workgroup per CU (the LDS window allows no more); idle workgroups help unfinished scans
+  const int grid = helpers ? ctx->num_cus : (B < ctx->num_cus ? B : ctx->num_cus);
 #define NDT_LAUNCH(S_, I_)                                                                           \
-  ndt_align_kernel<S_, I_><<<B, kBlock, 0, st>>>(V, O, scans, offsets, B, shared_scan, inits, out, trace, \
-                                                 trace_cap, trace_rows, sorted, prof)
+  ndt_align_kernel<S_, I_><<<grid, kBlock, 0, st>>>(V, O, scans, offsets, B, shared_scan, inits, out, trace, \
+                                                    trace_cap, trace_rows, sorted, ws, helpers, prof)
   if (sse && incl) NDT_LAUNCH(true, true);
   else if (sse)    NDT_LAUNCH(true, false);
   else if (incl)   NDT_LAUNCH(false, true);
   else             NDT_LAUNCH(false, false);
 #undef NDT_LAUNCH
+  HIP_TRY(ctx, hipGetLastError());
+  return NDT_OK;
 }
 
 int upload_exp_table(ndt_ctx *ctx) {
@@ -1423,6 +1904,14 @@ int ndt_ctx_create(int device, ndt_ctx **out) {
   HIP_TRY(c, hipEventCreate(&c->ev0));
   HIP_TRY(c, hipEventCreate(&c->ev1));
   { int rc = upload_exp_table(c); if (rc) return rc; }
+  {
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, device));
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+    c->helpers = getenv("NDT_NO_HELPERS") ? 0 : kMaxHelpers;
+    if (getenv("NDT_MAX_HELPERS")) c->helpers = atoi(getenv("NDT_MAX_HELPERS"));
+    if (getenv("NDT_GRID")) c->num_cus = atoi(getenv("NDT_GRID"));
+  }
   *out = c;
   return NDT_OK;
 }
@@ -1435,7 +1924,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->own_stream) e = hipStreamDestroy(c->own_stream);
   if (c->ev0) e = hipEventDestroy(c->ev0);
   if (c->ev1) e = hipEventDestroy(c->ev1);
-  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted};
+  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_ws};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
   delete c;
@@ -1645,10 +2134,8 @@ int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, co
     if (rc) return rc;
     sorted = (float2 *)ctx->d_sorted;
   }
-  launch_align(map, st, scans, (const unsigned long long *)offsets, B, shared_scan, inits, out, nullptr, 0,
-               nullptr, sorted, nullptr);
-  HIP_TRY(ctx, hipGetLastError());
-  return NDT_OK;
+  return launch_align(ctx, map, st, scans, (const unsigned long long *)offsets, B, shared_scan, inits, out,
+                      nullptr, 0, nullptr, sorted, nullptr);
 }
 
 int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, const uint64_t *offsets,
@@ -1681,28 +2168,41 @@ int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, 
   // diagnostic phase timing (NDT_PROF=1): not part of the ABI, prints to stderr
   unsigned long long *d_prof = nullptr;
   const bool want_prof = getenv("NDT_PROF") != nullptr;
-  if (want_prof) HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 32));
+  if (want_prof) { HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 48)); HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, (size_t)B * 48, st)); }
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
   float2 *sorted = nullptr;
   if (!shared_scan) {
     if ((rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (size_t)offsets[nscan] * 8))) return rc;
     sorted = (float2 *)ctx->d_sorted;
   }
-  launch_align(map, st, (const float *)ctx->d_scan, (const unsigned long long *)ctx->d_off, B, shared_scan,
-               (const double *)ctx->d_init, (ndt_result *)ctx->d_res, d_trace, trace_cap, d_rows, sorted, d_prof);
-  HIP_TRY(ctx, hipGetLastError());
+  if ((rc = launch_align(ctx, map, st, (const float *)ctx->d_scan, (const unsigned long long *)ctx->d_off, B,
+                         shared_scan, (const double *)ctx->d_init, (ndt_result *)ctx->d_res, d_trace, trace_cap,
+                         d_rows, sorted, d_prof)))
+    return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
   if (want_prof) {
-    unsigned long long *hp = (unsigned long long *)malloc((size_t)B * 32);
-    HIP_TRY(ctx, hipMemcpy(hp, d_prof, (size_t)B * 32, hipMemcpyDeviceToHost));
-    double te = 0, ta = 0, tf = 0, ev = 0, worst = 0;
+    unsigned long long *hp = (unsigned long long *)malloc((size_t)B * 48);
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    HIP_TRY(ctx, hipMemcpy(hp, d_prof, (size_t)B * 48, hipMemcpyDeviceToHost));
+    double te = 0, ta = 0, tw = 0, ev = 0, sh = 0, hc = 0, worst = 0;
     for (int b = 0; b < B; ++b) {
-      te += hp[4 * b] * 0.01; ta += hp[4 * b + 1] * 0.01; tf += hp[4 * b + 2] * 0.01; ev += hp[4 * b + 3];
-      double tot = (hp[4 * b] + hp[4 * b + 1] + hp[4 * b + 2]) * 0.01;
+      te += hp[4 * b] * 0.01; ta += (hp[4 * b + 1] & 0xFFFFFFFFull) * 0.01; tw += 0;
+      ev += (double)(hp[4 * b + 3] & 0xFFFF); sh += (double)((hp[4 * b + 3] >> 16) & 0xFFFF); hc += (double)(hp[4 * b + 3] >> 32);
+      double tot = (hp[4 * b] + (hp[4 * b + 1] & 0xFFFFFFFFull)) * 0.01;
       if (tot > worst) worst = tot;
     }
-    fprintf(stderr, "[NDT_PROF] B=%d evals=%.0f | per eval: pass+reduce %.2f us, advance %.2f us | fitness %.2f us/scan | slowest scan %.1f us\n",
-            B, ev, te / ev, ta / ev, tf / B, worst);
+    for (int rep = 0; rep < 6 && rep < B; ++rep) {      // the longest scans
+      int best = -1; double bt = -1;
+      for (int b = 0; b < B; ++b) { double tot = (hp[4 * b] + (hp[4 * b + 1] & 0xFFFFFFFFull)) * 0.01; if (tot > bt && !(hp[4 * b + 3] >> 63)) { bt = tot; best = b; } }
+      if (best < 0) break;
+      fprintf(stderr, "[NDT_PROF]   scan %3d: %.0f us (fitness pass %.0f us, window spilled %d), passes %llu, shared %llu, helper units %llu, first shared pass at %.0f us (scan started %.0f, first helper attached %.0f, its window ready %.0f)\n", best, bt,
+              (double)((hp[4 * best + 1] >> 32) & 0x7FFFFFFFull) * 0.01, (int)(hp[4 * best + 1] >> 63),
+              hp[4 * best + 3] & 0xFFFF, (hp[4 * best + 3] >> 16) & 0xFFFF, (hp[4 * best + 3] >> 32) & 0x7FFFFFFF, (double)(hp[4 * best + 2] >> 32) * 0.01, (double)(hp[4 * best + 2] & 0xFFFFFFFFull) * 0.01,
+              (double)hp[4 * B + 2 * best] * 0.01, (double)hp[4 * B + 2 * best + 1] * 0.01);
+      hp[4 * best + 3] |= 1ull << 63;
+    }
+    fprintf(stderr, "[NDT_PROF] B=%d passes=%.0f (+fitness) | per pass: compute+combine %.2f us, advance %.2f us | shared passes %.0f, helper chunks %.0f, owner wait %.2f us per shared pass | slowest scan %.1f us\n",
+            B, ev, te / (ev + B), ta / ev, sh, hc, sh > 0 ? tw / sh : 0.0, worst);
     free(hp);
     hipError_t e = hipFree(d_prof); (void)e;
   }
