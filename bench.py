@@ -48,7 +48,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from ndt_slam_amd import capi, synth
+    from ndt_slam_amd import capi, shard, synth
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -82,7 +82,6 @@ def main():
     d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
     d_init = torch.from_numpy(inits).to(dev)
     d_res = torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
-    gathered = [torch.zeros_like(d_res) for _ in range(world)] if (world > 1 and rank == 0) else None
     torch.cuda.synchronize()
     gmap = capi.Map(ctx, params=prm, dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
 
@@ -99,7 +98,7 @@ def main():
                              d_res.data_ptr(), stream=stream.cuda_stream)
         ev_a[2 * i + 1].record(stream)
         if world > 1:    # gather of poses (the only collective on this path)
-            dist.gather(d_res, gathered, dst=0)
+            shard.gather_results(d_res, dst=0)
 
     def fence():
         torch.cuda.synchronize()

@@ -1522,11 +1522,28 @@ __device__ __forceinline__ int voxel_of(const GridDims &G, float2 p) {
   return iy * G.div_x + ix;
 }
 
-__global__ void map_count_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims G,
-                                 int *__restrict__ count) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    int v = voxel_of(G, load_pt(xy, stride, i));
-    if (v >= 0) atomicAdd(&count[v], 1);
+// Consecutive cloud points usually fall in the same voxel (a map is appended scan by scan, wall by
+// wall), so a wave first merges runs of equal voxel keys among its 64 consecutive points and issues
+// one atomic per run instead of one per point.
+__device__ __forceinline__ void wave_runs(int v, int lane, int &head, int &len) {
+  const int prev = __shfl_up(v, 1);
+  const bool is_head = (lane == 0) || (v != prev);
+  const unsigned long long heads = __ballot(is_head);
+  const unsigned long long below = heads & ((2ull << lane) - 1ull);      // heads at or below this lane
+  head = 63 - __builtin_clzll(below);
+  const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+  len = above ? (lane + 1 + __builtin_ctzll(above)) - lane : 64 - lane;  // valid in head lanes
+}
+
+__global__ void __launch_bounds__(256)
+map_count_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims G, int *__restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  const size_t nround = (n + 63) / 64 * 64;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nround; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = i < n ? voxel_of(G, load_pt(xy, stride, i)) : -2;
+    int head, len;
+    wave_runs(v, lane, head, len);
+    if (head == lane && v >= 0) atomicAdd(&count[v], len);
   }
 }
 
@@ -1596,14 +1613,19 @@ scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ 
   if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
 }
 
-__global__ void map_scatter_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims G,
-                                   const int *__restrict__ start, int *__restrict__ fill,
-                                   int *__restrict__ perm) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    int v = voxel_of(G, load_pt(xy, stride, i));
-    if (v < 0) continue;
-    int slot = start[v] + atomicAdd(&fill[v], 1);
-    perm[slot] = (int)i;
+__global__ void __launch_bounds__(256)
+map_scatter_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims G,
+                   const int *__restrict__ start, int *__restrict__ fill, int *__restrict__ perm) {
+  const int lane = threadIdx.x & 63;
+  const size_t nround = (n + 63) / 64 * 64;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nround; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = i < n ? voxel_of(G, load_pt(xy, stride, i)) : -2;
+    int head, len;
+    wave_runs(v, lane, head, len);
+    int base = 0;
+    if (head == lane && v >= 0) base = start[v] + atomicAdd(&fill[v], len);   // one slot range per run
+    base = __shfl(base, head);
+    if (v >= 0) perm[base + (lane - head)] = (int)i;                          // cloud order kept inside a run
   }
 }
 
@@ -1701,14 +1723,21 @@ map_finalize_kernel(const float *__restrict__ xy, size_t stride, GridDims G, Lea
     float fx = 0.f, fy = 0.f;
     double sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0, szz = 0;
     if (L.cov_init_identity) { sxx = 1.0; syy = 1.0; szz = 1.0; }
-    for (int s = s0; s < s1; ++s) {
-      float2 p = load_pt(xy, stride, (size_t)perm_sorted[s]);
+    auto add = [&](int s, float2 p) {           // strictly in cloud order: these sums define the voxel
       pts[s] = p;
       fx += p.x; fy += p.y;
-      double X = (double)p.x, Y = (double)p.y;
+      const double X = (double)p.x, Y = (double)p.y;
       sx += X; sy += Y;
       sxx += X * X; sxy += X * Y; syy += Y * Y;
+    };
+    int s = s0;
+    for (; s + 4 <= s1; s += 4) {               // four gathers in flight
+      const int i0 = perm_sorted[s], i1 = perm_sorted[s + 1], i2 = perm_sorted[s + 2], i3 = perm_sorted[s + 3];
+      const float2 p0 = load_pt(xy, stride, (size_t)i0), p1 = load_pt(xy, stride, (size_t)i1);
+      const float2 p2 = load_pt(xy, stride, (size_t)i2), p3 = load_pt(xy, stride, (size_t)i3);
+      add(s, p0); add(s + 1, p1); add(s + 2, p2); add(s + 3, p3);
     }
+    for (; s < s1; ++s) add(s, load_pt(xy, stride, (size_t)perm_sorted[s]));
     if (n >= L.min_pts) {
       const int ix = (int)(g % G.div_x), iy = (int)(g / G.div_x);
       const size_t pg = (size_t)(iy + 2) * G.gw + (ix + 2);

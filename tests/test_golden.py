@@ -1,0 +1,82 @@
+"""Golden vectors (tests/golden/c1_golden.npz, made by tests/golden/make_golden.py from the CPU
+oracle -- the reference has none).  CPU: the oracle still reproduces them.  GPU: the HIP path
+matches them through the C ABI."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+def check_results(res, gold_res, exact_counts=True):
+    for b in range(len(gold_res)):
+        r, g = res[b], gold_res[b]
+        d = r["pose"] - g["pose"]
+        assert abs(d[0]) <= 1e-4 and abs(d[1]) <= 1e-4            # north_star: 1e-4 m
+        assert abs((d[2] + math.pi) % (2 * math.pi) - math.pi) <= 1e-4   # 1e-4 rad
+        if exact_counts:
+            assert (r["iters"], r["ref_evals"], r["converged"]) == (g["iters"], g["ref_evals"], g["converged"])
+            assert (r["T00"], r["T10"], r["T03"], r["T13"]) == (g["T00"], g["T10"], g["T03"], g["T13"])
+            assert r["fitness"] == pytest.approx(g["fitness"], rel=1e-10)
+            assert r["score"] == pytest.approx(g["score"], rel=1e-9)
+            assert r["H"] == pytest.approx(g["H"], rel=1e-7, abs=1e-8 * np.abs(g["H"]).max())
+
+
+def test_generator_is_stable(gold):
+    """The synthetic inputs are part of the fixture: the generator must keep producing them."""
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C1"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    assert np.array_equal(m, gold["map_xy"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    scans, off, truths, inits = sf.batch(0, 8)
+    assert np.array_equal(scans, gold["scans"]) and np.array_equal(inits, gold["inits"])
+
+
+def test_oracle_reproduces_golden(oracle, gold):
+    M = oracle.Map(gold["map_xy"], oracle.default_params(resolution=float(gold["resolution"])))
+    i = M.info()
+    assert [i.min_bx, i.min_by, i.div_x, i.div_y, i.n_cells, i.n_valid] == gold["grid"].tolist()
+    t = M.export()
+    assert np.array_equal(t["idx"], gold["cell_idx"]) and np.array_equal(t["npts"], gold["cell_npts"])
+    assert np.array_equal(t["cent"], gold["cell_cent"])
+    assert t["mean"] == pytest.approx(gold["cell_mean"], rel=1e-14, abs=1e-14)
+    assert t["icov"] == pytest.approx(gold["cell_icov"], rel=1e-10, abs=1e-300)
+    res = M.align_batch(gold["scans"], gold["offsets"], gold["inits"])
+    check_results(res, gold["results"])
+    _, tr = M.align(gold["scans"][:int(gold["offsets"][1])], gold["inits"][0], trace_cap=256)
+    assert tr[:, 0] == pytest.approx(gold["trace0"][:, 0], rel=1e-9, abs=1e-12)
+    for b in range(3):
+        sc = gold["scans"][int(gold["offsets"][b]):int(gold["offsets"][b + 1])]
+        s, g, H, pairs = M.eval_at(sc, gold["inits"][b])
+        e = gold["evals"][b]
+        assert s == pytest.approx(e[0], rel=1e-12) and pairs == e[13]
+        assert g == pytest.approx(e[1:4], rel=1e-10, abs=1e-10)
+    assert np.array_equal(oracle.approx_voxel_filter(gold["scans"][:int(gold["offsets"][1])], 0.05), gold["filtered0"])
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_golden(gold):
+    from ndt_slam_amd import capi
+    ctx = capi.Context(0)
+    gm = capi.Map(ctx, gold["map_xy"], capi.default_params(resolution=float(gold["resolution"])))
+    t = gm.export()
+    assert np.array_equal(t["idx"], gold["cell_idx"]) and np.array_equal(t["cent"], gold["cell_cent"])
+    assert np.array_equal(t["mean"], gold["cell_mean"])
+    res, traces = gm.align_batch(gold["scans"], gold["offsets"], gold["inits"], trace_cap=256)
+    check_results(res, gold["results"])
+    assert traces[0][:, 0] == pytest.approx(gold["trace0"][:, 0], rel=1e-8, abs=1e-12)
+    for b in range(3):
+        sc = gold["scans"][int(gold["offsets"][b]):int(gold["offsets"][b + 1])]
+        s, g, H, pairs = gm.eval_at(sc, gold["inits"][b])
+        e = gold["evals"][b]
+        assert s == pytest.approx(e[0], rel=1e-11) and pairs == e[13]
+        assert g == pytest.approx(e[1:4], rel=1e-8, abs=1e-9 * np.abs(e[1:4]).max())
+        assert H.ravel() == pytest.approx(e[4:13], rel=1e-8, abs=1e-9 * np.abs(e[4:13]).max())

@@ -1,0 +1,71 @@
+"""The N > 1 path on CPU: world_size-2 `gloo` processes shard a batch, match their shards (with the
+CPU oracle standing in for the kernel -- this test is about the scatter / gather bookkeeping) and
+gather the result records; rank 0 must end up with exactly the single-process results."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ndt_slam_amd import shard
+
+
+def test_shard_bounds_partition():
+    for total in (0, 1, 7, 256, 2048, 4096):
+        for world in (1, 2, 3, 4, 8):
+            cuts = [shard.shard_bounds(total, world, r) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == total
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, outdir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ndt_slam_amd import synth
+    from oracle import ndt_oracle as O
+    cfg = synth.CONFIGS["C1"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])                # same map on every rank
+    om = O.Map(m, O.default_params(resolution=cfg["resolution"]))
+    B = 7                                                         # ragged split: 4 + 3
+    if rank == 0:
+        sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+        scans, off, truths, inits = sf.batch(0, B)
+        # ragged scans too: drop a few points of scan 2
+        keep = np.ones(len(scans), bool); keep[int(off[2]):int(off[2]) + 17] = False
+        lens = np.diff(off.astype(np.int64)); lens[2] -= 17
+        scans = scans[keep]; off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    else:
+        scans = off = inits = None
+    sc, of, ini = shard.scatter_batch(scans, off, inits, src=0)
+    res = om.align_batch(sc, of, ini)
+    pad = 4 - len(res)                                            # equal-size records for gather
+    buf = np.zeros(4 * O.RESULT_DTYPE.itemsize, np.uint8)
+    buf[:len(res) * O.RESULT_DTYPE.itemsize] = np.frombuffer(res.tobytes(), np.uint8)
+    got = shard.gather_results(torch.from_numpy(buf), dst=0)
+    best = shard.best_hypothesis(res["trans_prob"], shard.shard_bounds(B, world, rank)[0])
+    if rank == 0:
+        parts = []
+        for r in range(world):
+            lo, hi = shard.shard_bounds(B, world, r)
+            parts.append(np.frombuffer(got[r].numpy().tobytes(), O.RESULT_DTYPE)[:hi - lo])
+        allres = np.concatenate(parts)
+        ref = om.align_batch(scans, off, inits)
+        ok = allres.tobytes() == ref.tobytes() and best[1] == int(np.argmax(ref["trans_prob"]))
+        open(os.path.join(outdir, "ok"), "w").write("1" if ok else "0")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_scatter_match_gather(tmp_path, oracle):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert open(os.path.join(str(tmp_path), "ok")).read() == "1"
