@@ -95,8 +95,10 @@ __device__ __forceinline__ float2 load_pt(const float *xy, size_t stride, size_t
 __device__ __forceinline__ Tf32 tf_from_p(const double p[3]) {
   Tf32 t;
   float yaw = (float)p[2];
-  t.c = (float)cos((double)yaw);
-  t.s = (float)sin((double)yaw);
+  double sd, cd;
+  sincos((double)yaw, &sd, &cd);
+  t.c = (float)cd;
+  t.s = (float)sd;
   t.tx = (float)p[0];
   t.ty = (float)p[1];
   return t;
@@ -122,7 +124,7 @@ __device__ __forceinline__ bool finite2(float x, float y) {
 
 __device__ __forceinline__ void angle_cs(double snap, double yaw, double &c, double &s) {
   if (fabs(yaw) < snap) { c = 1.0; s = 0.0; }
-  else { c = cos(yaw); s = sin(yaw); }
+  else { sincos(yaw, &s, &c); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -632,22 +634,40 @@ __device__ __forceinline__ double yaw_from_T(float T00, float T10) {
 // still hold a closer point (box-distance pruning), then whole rings while the best distance
 // exceeds the ring bound.
 // ------------------------------------------------------------------------------------------
+// The cost of this search is the number of (lane, cache line) look-ups of its divergent loads --
+// the CU's vector L1 serves about one line per clock -- so everything is fetched as wide as the
+// layout allows: a bucket's points two per 16-byte load, and the offsets of up to three
+// neighbouring voxels of a row in one 16-byte load (pt_start carries 4 readable ints before its
+// first entry and 3 after its last one).
+struct __attribute__((packed, aligned(4))) I4u { int x, y, z, w; };
+struct __attribute__((packed, aligned(4))) I2u { int x, y; };
+__device__ __forceinline__ I4u ld_i4u(const int *p) { I4u v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ I2u ld_i2u(const int *p) { I2u v; __builtin_memcpy(&v, p, 8); return v; }
+
+__device__ __forceinline__ float sq_dist(float qx, float qy, float px, float py) {
+  const float ex = qx - px, ey = qy - py;
+  return ex * ex + ey * ey;
+}
+
+// min over the points pts[s .. se) of the float32 squared distance to (qx, qy)
 __device__ __forceinline__ float scan_bucket(const float2 *__restrict__ pts, int s, int se, float qx,
                                              float qy, float best) {
-  for (; s + 4 <= se; s += 4) {              // four independent loads in flight
-    const float2 p0 = pts[s], p1 = pts[s + 1], p2 = pts[s + 2], p3 = pts[s + 3];
-    float ex, ey, d0, d1, d2, d3;
-    ex = qx - p0.x; ey = qy - p0.y; d0 = ex * ex + ey * ey;
-    ex = qx - p1.x; ey = qy - p1.y; d1 = ex * ex + ey * ey;
-    ex = qx - p2.x; ey = qy - p2.y; d2 = ex * ex + ey * ey;
-    ex = qx - p3.x; ey = qy - p3.y; d3 = ex * ex + ey * ey;
+  if (s >= se) return best;
+  if (s & 1) { const float2 p = pts[s]; best = fminf(best, sq_dist(qx, qy, p.x, p.y)); ++s; }
+  const float4 *__restrict__ p4 = reinterpret_cast<const float4 *>(pts + s);   // 16-byte aligned
+  const int npair = (se - s) >> 1;
+  int i = 0;
+  for (; i + 2 <= npair; i += 2) {           // four points, two loads in flight
+    const float4 a = p4[i], b = p4[i + 1];
+    const float d0 = sq_dist(qx, qy, a.x, a.y), d1 = sq_dist(qx, qy, a.z, a.w);
+    const float d2 = sq_dist(qx, qy, b.x, b.y), d3 = sq_dist(qx, qy, b.z, b.w);
     best = fminf(best, fminf(fminf(d0, d1), fminf(d2, d3)));
   }
-  for (; s < se; ++s) {
-    const float2 p = pts[s];
-    const float ex = qx - p.x, ey = qy - p.y;
-    best = fminf(best, ex * ex + ey * ey);
+  if (i < npair) {
+    const float4 a = p4[i];
+    best = fminf(best, fminf(sq_dist(qx, qy, a.x, a.y), sq_dist(qx, qy, a.z, a.w)));
   }
+  if ((se - s) & 1) { const float2 p = pts[se - 1]; best = fminf(best, sq_dist(qx, qy, p.x, p.y)); }
   return best;
 }
 
@@ -658,7 +678,9 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
   const bool inside = (cx == cx0) && (cy == cy0);
   const int *__restrict__ ps = M.pt_start;
   const size_t gh = (size_t)cy * M.div_x + cx;
-  float best = scan_bucket(M.pts, ps[gh], ps[gh + 1], qx, qy, INFINITY);
+  // offsets of (cx-1, cx, cx+1) of the home row in one load: [left, home) [home, right) [right, end)
+  const I4u h = ld_i4u(ps + gh - 1);
+  float best = scan_bucket(M.pts, h.y, h.z, qx, qy, INFINITY);
   // distances from the query to the four walls of its voxel, shrunk by 1e-3 leaf so that a point
   // the float32 voxel rounding put on the other side of a wall is never pruned away
   const float L = M.leaf, slack = 1e-3f * L;
@@ -666,21 +688,22 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
   float wl = fmaxf(fx - slack, 0.f), wr = fmaxf(L - fx - slack, 0.f);
   float wd = fmaxf(fy - slack, 0.f), wu = fmaxf(L - fy - slack, 0.f);
   if (!inside) { wl = wr = wd = wu = 0.f; }            // clamped query: no pruning
+  const float wmin = fminf(fminf(wl, wr), fminf(wd, wu));
+  if (!(wmin * wmin < best)) return best;              // no other voxel can hold a closer point
+  // ring 1: left / right voxel of the home row, then the rows below and above as one range each,
+  // every voxel pruned by its box distance
+  const bool has_l = cx > 0, has_r = cx + 1 < M.div_x;
+  if (has_l && wl * wl < best) best = scan_bucket(M.pts, h.x, h.y, qx, qy, best);
+  if (has_r && wr * wr < best) best = scan_bucket(M.pts, h.z, h.w, qx, qy, best);
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy) {
+  for (int dy = -1; dy <= 1; dy += 2) {
     const int yy = cy + dy;
-    if (yy < 0 || yy >= M.div_y) continue;
-    const float by = dy < 0 ? wd : (dy > 0 ? wu : 0.f);
-#pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      if (dx == 0 && dy == 0) continue;
-      const int xx = cx + dx;
-      if (xx < 0 || xx >= M.div_x) continue;
-      const float bx = dx < 0 ? wl : (dx > 0 ? wr : 0.f);
-      if (!(bx * bx + by * by < best)) continue;       // that voxel cannot hold a closer point
-      const size_t g = (size_t)yy * M.div_x + xx;
-      best = scan_bucket(M.pts, ps[g], ps[g + 1], qx, qy, best);
-    }
+    const float by = dy < 0 ? wd : wu;
+    if (yy < 0 || yy >= M.div_y || !(by * by < best)) continue;
+    const I4u o = ld_i4u(ps + (size_t)yy * M.div_x + cx - 1);
+    const int sa = (has_l && wl * wl + by * by < best) ? o.x : o.y;
+    const int sb = (has_r && wr * wr + by * by < best) ? o.w : o.z;
+    best = scan_bucket(M.pts, sa, sb, qx, qy, best);
   }
   const double Ld = (double)L;
   const int rmax = M.div_x > M.div_y ? M.div_x : M.div_y;
@@ -695,14 +718,17 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
       const float rem = best - by * by;
       if (!(rem > 0.f)) continue;
       const int hw = (int)fminf(sqrtf(rem) / L, 1.0e6f) + 1;   // columns farther than hw cannot matter
-      const size_t g = (size_t)yy * M.div_x;
+      const int *__restrict__ row = ps + (size_t)yy * M.div_x;
       if (yy == y0 || yy == y1) {
         int xa = x0 > cx - hw ? x0 : cx - hw, xb = x1 < cx + hw ? x1 : cx + hw;
         xa = xa < 0 ? 0 : xa; xb = xb >= M.div_x ? M.div_x - 1 : xb;
-        if (xa <= xb) best = scan_bucket(M.pts, ps[g + xa], ps[g + xb + 1], qx, qy, best);
+        if (xa <= xb) { const int sa = row[xa], sb = row[xb + 1]; best = scan_bucket(M.pts, sa, sb, qx, qy, best); }
       } else if (R <= hw) {
-        if (x0 >= 0 && x0 < M.div_x) best = scan_bucket(M.pts, ps[g + x0], ps[g + x0 + 1], qx, qy, best);
-        if (x1 >= 0 && x1 < M.div_x) best = scan_bucket(M.pts, ps[g + x1], ps[g + x1 + 1], qx, qy, best);
+        I2u a = {0, 0}, b = {0, 0};                     // both voxels' offsets in flight together
+        if (x0 >= 0) a = ld_i2u(row + x0);
+        if (x1 < M.div_x) b = ld_i2u(row + x1);
+        best = scan_bucket(M.pts, a.x, a.y, qx, qy, best);
+        best = scan_bucket(M.pts, b.x, b.y, qx, qy, best);
       }
     }
   }
@@ -797,6 +823,8 @@ struct Lds {
   double wtmp[kWaves * 12];        // helper waves: the unit just computed, before it is published
   double tot[12];                  // pass totals
   unsigned long long own_mask;     // units of the open pass computed by this workgroup
+  unsigned long long hpose[8];     // helper: pose block of epoch hep, staged by wave 0
+  unsigned hep;
   double etab[64];
 };
 
@@ -1104,7 +1132,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
                  float2 *__restrict__ sorted /* scratch, same offsets as scans; may be null */,
                  unsigned char *__restrict__ ws /* WsHeader, ScanCtl[B], unit totals[B][kUnits][12], marked-cell bitmaps[B][kRegionCells/32] */,
                  int allow_helpers /* 0: none; else max helper workgroups per scan */,
-                 unsigned long long *__restrict__ prof /* diagnostic: 4 words per scan */) {
+                 unsigned long long *__restrict__ prof /* diagnostic: 8 words per scan */) {
   __shared__ Lds L;
   __shared__ uint4 pool[kPoolBytes / 16];
   WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
@@ -1166,8 +1194,10 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       }
     }
     const Window W = window_of(L.RG, pool);
+    if (threadIdx.x == 0) L.sflag[1] = 0;            // helpers attached (refreshed during every advance)
     unsigned epoch = 1;
     u64 t_eval = 0, t_adv = 0, tt0 = 0, tt1 = 0, t_wait = 0, t_first_shared = 0, t_fit = 0;
+    u64 ts1 = 0, ts2 = 0, ts3 = 0, a_pro = 0, a_own = 0, a_wait = 0, a_comb = 0, a_adv = 0, a_n = 0;   // shared derivative passes (diagnostic)
     const u64 t_scan0 = wall_clock64() - t_start;
     unsigned n_shared = 0, n_helped = 0;
     bool fitness_done = false;
@@ -1178,7 +1208,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       if (threadIdx.x == 0) {
         L.PP.T = L.S.T; L.PP.cj = L.S.cj; L.PP.sj = L.S.sj; L.PP.ch = L.S.ch; L.PP.sh = L.S.sh;
         L.PP.kind = fit_pass ? 1 : 0;
-        const int h = allow_helpers >= 1000 ? 1 : (allow_helpers ? (int)rd32_fresh(&C->helpers) : 0);   // >= 1000: diagnostic, force shared passes
+        const int h = allow_helpers >= 1000 ? 1 : (allow_helpers ? L.sflag[1] : 0);   // >= 1000: diagnostic, force shared passes
         if (allow_helpers) st32(&C->passes, (u32)L.S.evals);
         // the fitness pass is the longest of a match and runs once: always open it to helpers, also to
         // those that attach while it is running
@@ -1198,6 +1228,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         }
       }
       __syncthreads();
+      if (prof) ts1 = wall_clock64();
       const int nhelp = L.sflag[0];
       const PassPose pp = L.PP;
       if (nhelp <= 0) {
@@ -1208,10 +1239,10 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         // shared pass: this workgroup's waves and the helpers' waves claim units from the ticket.
         // Waves beyond the owner's fair share hold back a moment so that helpers get theirs.
         ++epoch;
-        const int quota = (kWaves + nhelp) / (nhelp + 1);     // owner waves that start at once
-#ifndef NDT_NO_QUOTA_DELAY
-        if (wave >= quota) { const u64 w0 = wall_clock64(); while (wall_clock64() - w0 < 500) __builtin_amdgcn_s_sleep(16); }
-#endif
+        // the owner's fair share of the units, one per wave, starts at once; its other waves are a
+        // fallback for slow helpers and hold back
+        const int quota = (kUnits + nhelp) / (nhelp + 1);
+        if (wave >= quota) { const u64 w0 = wall_clock64(); while (wall_clock64() - w0 < 600) __builtin_amdgcn_s_sleep(16); }
         // (a counted loop on purpose: hipcc / ROCm 7.2 miscompiles `for (;;)` + break around
         // cross-lane work followed by a lane-0 LDS atomic -- tools/repro/ticket2.hip)
         for (int claims = 0; claims <= kUnits; ++claims) {
@@ -1225,6 +1256,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
           if (lane == 0) atomicOr(&L.own_mask, 1ull << idx);
         }
         __syncthreads();
+        if (prof) ts2 = wall_clock64();
         // wait for the units the helpers claimed (running waves are computing them)
         if (threadIdx.x == 0) {
           const u32 need = (u32)(kUnits - __builtin_popcountll(L.own_mask));
@@ -1240,6 +1272,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
           L.sflag[2] = bad;
         }
         __syncthreads();
+        if (prof) ts3 = wall_clock64();
         if (L.sflag[2]) { aborted = true; break; }
       }
       __syncthreads();
@@ -1261,11 +1294,17 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       if (prof) { tt1 = wall_clock64(); t_eval += tt1 - tt0; if (fit_pass) t_fit = tt1 - tt0; }
       if (!fit_pass) {
         if (threadIdx.x == 0) advance(L.S, P, M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
+        // meanwhile another wave fetches the number of attached helpers for the next pass
+        if (threadIdx.x == 64 && allow_helpers && allow_helpers < 1000) L.sflag[1] = (int)rd32_fresh(&C->helpers);
       } else {
         fitness_done = true;
       }
       __syncthreads();
-      if (prof) t_adv += wall_clock64() - tt1;
+      if (prof) {
+        const u64 te = wall_clock64();
+        t_adv += te - tt1;
+        if (nhelp > 0 && !fit_pass) { a_pro += ts1 - tt0; a_own += ts2 - ts1; a_wait += ts3 - ts2; a_comb += tt1 - ts3; a_adv += te - tt1; a_n += 1; }
+      }
     }
     // ---- result record; close the scan ----
     if (threadIdx.x == 0) {
@@ -1293,8 +1332,11 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         __hip_atomic_fetch_add(&hdr->done, 1u, NDT_RLX, NDT_AGENT);
       }
       if (prof) {
-        prof[4 * b + 0] = t_eval; prof[4 * b + 1] = t_adv | (t_fit << 32) | ((u64)(L.RG.nspill > 0) << 63); prof[4 * b + 2] = (t_first_shared << 32) | (t_scan0 & 0xFFFFFFFFull);
-        prof[4 * b + 3] = (unsigned long long)S.evals | ((u64)n_shared << 16) | ((u64)n_helped << 32);
+        prof[8 * b + 0] = t_eval; prof[8 * b + 1] = t_adv | (t_fit << 32) | ((u64)(L.RG.nspill > 0) << 63); prof[8 * b + 2] = (t_first_shared << 32) | (t_scan0 & 0xFFFFFFFFull);
+        prof[8 * b + 3] = (unsigned long long)S.evals | ((u64)n_shared << 16) | ((u64)n_helped << 32);
+        prof[8 * b + 6] = t_wait; prof[8 * b + 7] = wall_clock64() - t_start;
+        u64 *p2 = prof + 8 * (size_t)B + 8 * (size_t)b;
+        p2[0] = a_n; p2[1] = a_pro; p2[2] = a_own; p2[3] = a_wait; p2[4] = a_comb; p2[5] = a_adv;
       }
     }
   }
@@ -1332,7 +1374,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         } else {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // geometry + ordered copy of the owner
           drain_vmem();
-          if (prof && h == 0) prof[4 * B + 2 * b] = wall_clock64() - t_start;
+          if (prof && h == 0) prof[8 * b + 4] = wall_clock64() - t_start;
           code = b;
         }
       }
@@ -1368,8 +1410,10 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     __syncthreads();
     fill_window(M, L, pool);
     const Window W = window_of(L.RG, pool);
-    if (prof && threadIdx.x == 0 && prof[4 * B + 2 * vb + 1] == 0) prof[4 * B + 2 * vb + 1] = wall_clock64() - t_start;
+    if (prof && threadIdx.x == 0 && prof[8 * vb + 5] == 0) prof[8 * vb + 5] = wall_clock64() - t_start;
     u64 *vtot = utot + (size_t)vb * kUnits * 12;
+    if (threadIdx.x == 0) L.hep = 0u;
+    __syncthreads();
     {
       unsigned my_ep = 0, polls = 0;
       PassPose pp; pp.kind = 0; pp.cj = pp.sj = pp.ch = pp.sh = 0.0; pp.T.c = pp.T.s = pp.T.tx = pp.T.ty = 0.f;
@@ -1380,21 +1424,57 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         const u32 ep = (u32)(v >> 32), idx = (u32)v;
         if (ep == kEpochDone) break;
         if (idx >= (u32)kUnits) {
-          // nothing on offer: wait for the next epoch (or the end of the scan)
+          // nothing on offer: wait for the next epoch (or the end of the scan).  Wave 0 polls the
+          // ticket line, copies the new pose block to LDS and raises L.hep; the other waves watch
+          // L.hep, so one load per helper workgroup is in flight on the owner's line.
           int bad = 0;
-          if (lane == 0) {
-            while ((u32)(ld64(&C->ticket) >> 32) == ep) {
-              if (watchdog(hdr, t_start, polls)) { bad = 1; break; }
-              __builtin_amdgcn_s_sleep(48);
+          if (wave == 0) {
+            u32 nep = ep;
+            if (lane == 0) {
+              while ((nep = (u32)(ld64(&C->ticket) >> 32)) == ep) {
+                if (watchdog(hdr, t_start, polls)) { bad = 1; break; }
+                __builtin_amdgcn_s_sleep(2);
+              }
+            }
+            nep = __builtin_amdgcn_readfirstlane(nep);
+            bad = __builtin_amdgcn_readfirstlane(bad);
+            if (!bad && nep == kEpochDone) {
+              if (lane == 0) __hip_atomic_store(&L.hep, nep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else if (!bad) {
+              u64 w = 0;
+              if (lane < 7) w = ld64(lane < 6 ? &C->pose[lane] : &C->kind);
+              if (lane < 7) L.hpose[lane] = w;
+              __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the pose words are in LDS
+              // the pose block belongs to epoch nep only if the ticket still shows nep afterwards
+              u32 chk = nep;
+              if (lane == 0) chk = (u32)(ld64(&C->ticket) >> 32);
+              chk = __builtin_amdgcn_readfirstlane(chk);
+              if (lane == 0 && chk == nep) __hip_atomic_store(&L.hep, nep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+          } else {
+            if (lane == 0) {
+              const u64 w0 = wall_clock64();
+              for (int it = 0; it < (1 << 24); ++it) {       // counted: ends by the clock long before
+                const u32 hs = __hip_atomic_load(&L.hep, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (hs == ep + 1u || hs == kEpochDone) break;
+                if (wall_clock64() - w0 > 1000) break;       // 10 us: look at the ticket ourselves again
+                __builtin_amdgcn_s_sleep(1);
+              }
             }
           }
-          bad = __builtin_amdgcn_readfirstlane(bad);
           if (bad) break;
           continue;
         }
         if (ep != my_ep) {                                   // first unit of a new epoch: its pose block
           u64 w = 0;
-          if (lane < 7) w = ld64(lane < 6 ? &C->pose[lane] : &C->kind);
+          const bool staged = __hip_atomic_load(&L.hep, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == ep;
+          if (staged) { if (lane < 7) w = L.hpose[lane]; }
+          else {
+            // this wave is first to see the epoch (it holds a unit of it, so the block is stable): stage it
+            if (lane < 7) { w = ld64(lane < 6 ? &C->pose[lane] : &C->kind); L.hpose[lane] = w; }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            if (lane == 0) __hip_atomic_store(&L.hep, ep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
           const u64 w0 = __shfl(w, 0), w1 = __shfl(w, 1), w2 = __shfl(w, 2), w3 = __shfl(w, 3), w4 = __shfl(w, 4),
                     w5 = __shfl(w, 5), w6 = __shfl(w, 6);
           pp.T.c = __uint_as_float((u32)w0); pp.T.s = __uint_as_float((u32)(w0 >> 32));
@@ -1610,7 +1690,7 @@ scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ 
   int run = tile_off[blockIdx.x] + sh[threadIdx.x] - s;
 #pragma unroll
   for (int k = 0; k < kScanPer; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
-  if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = *total;
+  if (blockIdx.x == 0 && threadIdx.x < 4) out[n + threadIdx.x] = *total;   // out[n], + 3 readable copies
 }
 
 __global__ void __launch_bounds__(256)
@@ -2035,7 +2115,7 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
     int rc;
     const size_t ntiles_ = (ng + kScanTile - 1) / kScanTile;
     if ((rc = ensure_t(ctx, &m->count, &m->count_cap, ng + 1))) return rc;
-    if ((rc = ensure_t(ctx, &m->start, &m->start_cap, ng + 1))) return rc;
+    if ((rc = ensure_t(ctx, &m->start, &m->start_cap, ng + 1 + 8))) return rc;   // 4 readable ints before, 3 after (nearest_sq)
     if ((rc = ensure_t(ctx, &m->fill, &m->fill_cap, ng + 1))) return rc;
     if ((rc = ensure_t(ctx, &m->npts_grid, &m->npts_cap, ng + 1))) return rc;
     if ((rc = ensure_t(ctx, &m->tile, &m->tile_cap, ntiles_ + 1))) return rc;
@@ -2056,15 +2136,17 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
   const int ntiles = (int)((ng + kScanTile - 1) / kScanTile);
   scan_tile_sums_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile);
   scan_tile_offsets_kernel<<<1, 1024, 0, st>>>(m->tile, ntiles, m->total);
-  scan_apply_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, m->start, m->total);
-  map_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, m->start, m->fill, m->perm);
-  map_order_kernel<<<(unsigned)((ng + 3) / 4), 256, 0, st>>>(m->start, ng, m->perm, m->perm_sorted);
+  HIP_TRY(ctx, hipMemsetAsync(m->start, 0, 4 * sizeof(int), st));
+  int *const start = m->start + 4;
+  scan_apply_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, start, m->total);
+  map_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, start, m->fill, m->perm);
+  map_order_kernel<<<(unsigned)((ng + 3) / 4), 256, 0, st>>>(start, ng, m->perm, m->perm_sorted);
 
   // 4. per-voxel statistics -> centroid grid + cell records + bucketed raw points
   LeafParams L;
   L.min_pts = prm->min_pts; L.cov_unbiased = prm->cov_unbiased; L.cov_init_identity = prm->cov_init_identity;
   L.eig_mult = prm->eig_mult;
-  map_finalize_kernel<<<(unsigned)((ng + 255) / 256), 256, 0, st>>>(xy, stride, G, L, m->start, m->perm_sorted,
+  map_finalize_kernel<<<(unsigned)((ng + 255) / 256), 256, 0, st>>>(xy, stride, G, L, start, m->perm_sorted,
                                                                     m->pts, m->cent, m->rec, m->npts_grid,
                                                                     m->counters);
   HIP_TRY(ctx, hipGetLastError());
@@ -2075,7 +2157,7 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
   V.r2 = (float)((double)prm->resolution * (double)prm->resolution);
   V.radius_inclusive = prm->radius_inclusive; V.transform_sse = prm->transform_sse;
   V.min_bx = G.min_bx; V.min_by = G.min_by; V.div_x = G.div_x; V.div_y = G.div_y; V.gw = G.gw; V.gh = G.gh;
-  V.cent = m->cent; V.rec = m->rec; V.pt_start = m->start; V.pts = m->pts;
+  V.cent = m->cent; V.rec = m->rec; V.pt_start = start; V.pts = m->pts;
   gauss_constants(*prm, &V.d1, &V.d2);
   m->info.min_bx = G.min_bx; m->info.min_by = G.min_by; m->info.div_x = G.div_x; m->info.div_y = G.div_y;
   m->info.n_points = n;
@@ -2197,7 +2279,7 @@ int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, 
   // diagnostic phase timing (NDT_PROF=1): not part of the ABI, prints to stderr
   unsigned long long *d_prof = nullptr;
   const bool want_prof = getenv("NDT_PROF") != nullptr;
-  if (want_prof) { HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 48)); HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, (size_t)B * 48, st)); }
+  if (want_prof) { HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 128)); HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, (size_t)B * 128, st)); }
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
   float2 *sorted = nullptr;
   if (!shared_scan) {
@@ -2210,28 +2292,29 @@ int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, 
     return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
   if (want_prof) {
-    unsigned long long *hp = (unsigned long long *)malloc((size_t)B * 48);
+    unsigned long long *hp = (unsigned long long *)malloc((size_t)B * 128);
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    HIP_TRY(ctx, hipMemcpy(hp, d_prof, (size_t)B * 48, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hp, d_prof, (size_t)B * 128, hipMemcpyDeviceToHost));
     double te = 0, ta = 0, tw = 0, ev = 0, sh = 0, hc = 0, worst = 0;
     for (int b = 0; b < B; ++b) {
-      te += hp[4 * b] * 0.01; ta += (hp[4 * b + 1] & 0xFFFFFFFFull) * 0.01; tw += 0;
-      ev += (double)(hp[4 * b + 3] & 0xFFFF); sh += (double)((hp[4 * b + 3] >> 16) & 0xFFFF); hc += (double)(hp[4 * b + 3] >> 32);
-      double tot = (hp[4 * b] + (hp[4 * b + 1] & 0xFFFFFFFFull)) * 0.01;
+      te += hp[8 * b] * 0.01; ta += (hp[8 * b + 1] & 0xFFFFFFFFull) * 0.01; tw += hp[8 * b + 6] * 0.01;
+      ev += (double)(hp[8 * b + 3] & 0xFFFF); sh += (double)((hp[8 * b + 3] >> 16) & 0xFFFF); hc += (double)(hp[8 * b + 3] >> 32);
+      double tot = (hp[8 * b] + (hp[8 * b + 1] & 0xFFFFFFFFull)) * 0.01;
       if (tot > worst) worst = tot;
     }
     for (int rep = 0; rep < 6 && rep < B; ++rep) {      // the longest scans
       int best = -1; double bt = -1;
-      for (int b = 0; b < B; ++b) { double tot = (hp[4 * b] + (hp[4 * b + 1] & 0xFFFFFFFFull)) * 0.01; if (tot > bt && !(hp[4 * b + 3] >> 63)) { bt = tot; best = b; } }
+      for (int b = 0; b < B; ++b) { double tot = (hp[8 * b] + (hp[8 * b + 1] & 0xFFFFFFFFull)) * 0.01; if (tot > bt && !(hp[8 * b + 3] >> 63)) { bt = tot; best = b; } }
       if (best < 0) break;
       fprintf(stderr, "[NDT_PROF]   scan %3d: %.0f us (fitness pass %.0f us, window spilled %d), passes %llu, shared %llu, helper units %llu, first shared pass at %.0f us (scan started %.0f, first helper attached %.0f, its window ready %.0f)\n", best, bt,
-              (double)((hp[4 * best + 1] >> 32) & 0x7FFFFFFFull) * 0.01, (int)(hp[4 * best + 1] >> 63),
-              hp[4 * best + 3] & 0xFFFF, (hp[4 * best + 3] >> 16) & 0xFFFF, (hp[4 * best + 3] >> 32) & 0x7FFFFFFF, (double)(hp[4 * best + 2] >> 32) * 0.01, (double)(hp[4 * best + 2] & 0xFFFFFFFFull) * 0.01,
-              (double)hp[4 * B + 2 * best] * 0.01, (double)hp[4 * B + 2 * best + 1] * 0.01);
-      hp[4 * best + 3] |= 1ull << 63;
+              (double)((hp[8 * best + 1] >> 32) & 0x7FFFFFFFull) * 0.01, (int)(hp[8 * best + 1] >> 63),
+              hp[8 * best + 3] & 0xFFFF, (hp[8 * best + 3] >> 16) & 0xFFFF, (hp[8 * best + 3] >> 32) & 0x7FFFFFFF, (double)(hp[8 * best + 2] >> 32) * 0.01, (double)(hp[8 * best + 2] & 0xFFFFFFFFull) * 0.01,
+              (double)hp[8 * best + 4] * 0.01, (double)hp[8 * best + 5] * 0.01);
+      hp[8 * best + 3] |= 1ull << 63;
     }
     fprintf(stderr, "[NDT_PROF] B=%d passes=%.0f (+fitness) | per pass: compute+combine %.2f us, advance %.2f us | shared passes %.0f, helper chunks %.0f, owner wait %.2f us per shared pass | slowest scan %.1f us\n",
             B, ev, te / (ev + B), ta / ev, sh, hc, sh > 0 ? tw / sh : 0.0, worst);
+    if (const char *dump = getenv("NDT_PROF_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(hp, 128, (size_t)B, f); fclose(f); } }
     free(hp);
     hipError_t e = hipFree(d_prof); (void)e;
   }

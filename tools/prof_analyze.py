@@ -1,0 +1,26 @@
+"""Diagnostic: per-scan summary of an NDT_PROF_DUMP file (see tools/prof_phases.py)."""
+import sys
+import numpy as np
+raw = np.fromfile(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_dump_batch.bin", dtype=np.uint64)
+B = raw.size // 16
+hp = raw[:8 * B].reshape(B, 8)
+p2 = raw[8 * B:].reshape(B, 8).astype(np.float64)
+t_eval = hp[:, 0] * 0.01; t_adv = (hp[:, 1] & 0xFFFFFFFF) * 0.01; t_fit = ((hp[:, 1] >> 32) & 0x7FFFFFFF) * 0.01
+t0 = (hp[:, 2] & 0xFFFFFFFF) * 0.01
+ev = hp[:, 3] & 0xFFFF; nsh = (hp[:, 3] >> 16) & 0xFFFF; nhu = (hp[:, 3] >> 32) & 0x7FFFFFFF
+att = hp[:, 4] * 0.01; tw = hp[:, 6] * 0.01; tend = hp[:, 7] * 0.01
+pc = [10, 25, 50, 75, 90, 99, 100]
+print("setup us  mean %.0f" % t0.mean())
+print("end us    mean %.0f pcts" % tend.mean(), np.percentile(tend, pc).round())
+print("t_fit us  mean %.0f pcts" % t_fit.mean(), np.percentile(t_fit, pc).round())
+print("passes    mean %.1f pcts" % ev.mean(), np.percentile(ev, pc))
+if (att > 0).any():
+    print("first helper attach pcts", np.percentile(att[att > 0], pc).round(), "scans helped", (att > 0).sum())
+print("owner work per scan (setup+eval+adv) mean %.0f" % (t_eval + t_adv + t0).mean())
+print("finish histogram /100us", np.histogram(tend, bins=np.arange(0, 2000, 100))[0])
+for b in np.argsort(-tend)[:8]:
+    print("  scan %3d end %.0f passes %d shared %d fit %.0f attach %.0f wait %.0f" % (b, tend[b], ev[b], nsh[b], t_fit[b], att[b], tw[b]))
+n = p2[:, 0].sum()
+if n > 0:
+    print("shared derivative passes %d: prologue %.2f own units %.2f wait %.2f combine %.2f advance %.2f us (means)" %
+          (n, p2[:, 1].sum() / n * 0.01, p2[:, 2].sum() / n * 0.01, p2[:, 3].sum() / n * 0.01, p2[:, 4].sum() / n * 0.01, p2[:, 5].sum() / n * 0.01))
