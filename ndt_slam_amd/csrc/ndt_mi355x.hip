@@ -242,28 +242,6 @@ __device__ __forceinline__ void accumulate_cell(double d2, const double *__restr
   A.htt = __builtin_fma(e, tt, A.htt);
 }
 
-// Number of in-radius voxels of one source point at transform T (same tests as eval_point).
-template <bool SSE, bool INCL>
-__device__ __forceinline__ int count_in_radius(const MapView &M, const Window &W, const Tf32 &T, float x,
-                                               float y) {
-  float xt, yt;
-  tf_apply_t<SSE>(T, x, y, xt, yt);
-  const bool fin = finite2(xt, yt);
-  const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
-  const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
-  const int ix = (int)fx - M.min_bx, iy = (int)fy - M.min_by;
-  const bool ingrid = fin & (ix >= -1) & (ix <= M.div_x) & (iy >= -1) & (iy <= M.div_y);
-  if (!ingrid) return 0;
-  const float2 *grow = M.cent + (size_t)(iy + 1) * M.gw + (ix + 1);
-  unsigned mask = 0;
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int q = 0; q < 3; ++q) mask |= in_radius<INCL>(M.r2, xt, yt, grow[r * M.gw + q]) << (r * 3 + q);
-  (void)W;
-  return __builtin_popcount(mask);
-}
-
 // Everything one source point contributes to a derivative pass.
 // Fast path (window holds every occupied voxel, point's 3x3 neighbourhood inside it): slot
 // numbers, centroids and records all come from LDS.  Otherwise the same arithmetic reads the
@@ -767,20 +745,28 @@ constexpr unsigned long long kWatchTicks = 400000000ull;   // ~4 s of the 100 MH
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-// Per-scan control block: four 128-byte lines, so that the words hammered by different parties
-// (chunk claims and epoch polls / arrivals / attach counts / pose reads) never share a line.
+// Per-scan control block: four 128-byte lines, so that the words touched by different parties
+// (epoch polls / arrivals / attach + ready counts / pose reads) never share a line.
+//
+// The epoch word describes one SEGMENT of a pass -- units [ubeg, uend) split over the owner and the
+// first `h` registered helpers: participant k (0 = owner, k = helper rank + 1) computes the units
+// ubeg + k + j*(h+1).  The assignment is static (no claim atomics: a same-address agent-scope
+// read-modify-write costs ~0.1 us and 128 waves used to queue on it every pass); it is safe because a
+// helper only counts once it has registered in `ready`, after which it does nothing but poll this word.
 struct alignas(128) ScanCtl {
-  u64 ticket;        // line 0: (epoch << 32) | next chunk.  epoch 0: not open; kEpochDone: finished
+  u64 ticket;        // line 0: epoch << 32 | kind << 24 | h << 16 | uend << 8 | ubeg.  epoch 0: not open; kEpochDone: finished
   u64 pad0_[15];
-  u32 arrive;        // line 1: chunks published by helpers in the open epoch
+  u32 arrive;        // line 1: units published by helpers in the open epoch (one add per helper workgroup)
   u32 pad1_[31];
   u32 helpers;       // line 2: helper workgroups attached; geometry published by the owner's release
   int region[6];
   u32 passes;        //         passes the owner has run so far (helpers go where most were needed)
-  int pad2_[24];
+  u32 ready;         //         helpers whose window is staged; rank = order of registration
+  u32 phase;         //         1: the scan is in its fitness pass (a helper needs no window)
+  u32 use_sorted;    //         1: passes read the scan from the sorted scratch copy
+  int pad2_[21];
   u64 pose[6];       // line 3: float32 transform (c|s, tx|ty) and the four fp64 angle terms
-  u64 kind;          //         0: derivative pass, 1: fitness pass
-  u64 pad3_[9];
+  u64 pad3_[10];
 };
 static_assert(sizeof(ScanCtl) == 512, "ScanCtl is four 128-byte lines");
 
@@ -823,8 +809,10 @@ struct Lds {
   double wtmp[kWaves * 12];        // helper waves: the unit just computed, before it is published
   double tot[12];                  // pass totals
   unsigned long long own_mask;     // units of the open pass computed by this workgroup
-  unsigned long long hpose[8];     // helper: pose block of epoch hep, staged by wave 0
-  unsigned hep;
+  unsigned long long hpose[8];     // helper: pose block of the open epoch, staged by wave 0
+  unsigned long long hword;        // helper: epoch word seen by wave 0
+  int hrank;                       // helper: order of registration on its scan
+  int jnext, stop;                 // units of the open segment handed out so far; close the segment
   double etab[64];
 };
 
@@ -883,32 +871,6 @@ __device__ __forceinline__ void compute_region(const MapView &M, const Tf32 &T0,
     int cap = (kPoolBytes - slot_bytes) / (int)sizeof(CellEntry) - 2;   // last two = sentinels
     r.cap = cap > 0xFFF0 ? 0xFFF0 : cap;
     L.RG = r;
-  }
-  __syncthreads();
-}
-
-// Owner: mark the window cells the scan's points fall in at the first pose (one bit per cell,
-// kept in L.wmap).  fill_window gives LDS records only to occupied voxels within 2 cells of a
-// marked one (the voxels the scan can reach while its pose moves by up to ~1 m); a point that
-// later needs any other occupied voxel takes the HBM path for that pass.
-template <bool SSE>
-__device__ __forceinline__ void mark_wanted(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
-                                            int n, Lds &L) {
-  unsigned *wmap = reinterpret_cast<unsigned *>(L.wpart);
-  for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) wmap[i] = 0u;
-  __syncthreads();
-  const Region r = L.RG;
-  for (int i = threadIdx.x; i < n; i += kBlock) {
-    const float2 pt = scan[i];
-    float xt, yt;
-    tf_apply_t<SSE>(T0, pt.x, pt.y, xt, yt);
-    if (!finite2(xt, yt)) continue;
-    const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
-    const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
-    const int lx = (int)fx - M.min_bx - r.x0, ly = (int)fy - M.min_by - r.y0;
-    if (lx < 0 || lx >= r.rw || ly < 0 || ly >= r.rh) continue;
-    const int bit = ly * r.rw + lx;
-    atomicOr(&wmap[bit >> 5], 1u << (bit & 31));
   }
   __syncthreads();
 }
@@ -988,41 +950,85 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
   __syncthreads();
 }
 
-// Owner: order every lane's own points by their in-radius voxel count at the first pose.
-// A wave walks its 64 lanes' k-th points together and runs the pair body max-over-lanes times, so
-// lanes should meet points of equal count at equal k.  Each lane counting-sorts its own points
-// (descending count, stable) in groups of 32 and writes them, lane-contiguous, to the scratch copy
-// the passes then read.  No cross-lane traffic; the order depends only on scan, map and first pose.
-template <bool SSE, bool INCL>
-__device__ __forceinline__ void order_points(const MapView &M, const Window &W, const Tf32 &T0,
-                                             const float2 *__restrict__ scan, int n, float2 *__restrict__ sp) {
-  for (int g0 = 0; g0 * kBlock + (int)threadIdx.x < n; g0 += 32) {
-    u64 k_lo = 0, k_hi = 0, hist = 0;    // 4-bit counts of 32 points; 6-bit histogram fields
-    int cnt = 0;
-#pragma nounroll
-    for (int jj = 0; jj < 32; ++jj) {
-      const int i = (g0 + jj) * kBlock + threadIdx.x;
-      if (i >= n) break;
-      const float2 pt = scan[i];
-      const u64 K = (u64)count_in_radius<SSE, INCL>(M, W, T0, pt.x, pt.y);
-      if (jj < 16) k_lo |= K << (4 * jj); else k_hi |= K << (4 * (jj - 16));
-      hist += 1ull << (6 * K);
-      ++cnt;
-    }
-    u64 starts = 0; unsigned run = 0;
+// Owner: spatial order of the scan.  The points are sorted by the window cell they fall in at the
+// first pose (row-major cell order, input order kept inside a cell) and written to the scratch copy
+// every pass reads.  The 64 lanes of a wave then always work on neighbouring points -- a rigid
+// transform keeps neighbours together, so this holds at every later pose too -- which means: equal
+// in-radius voxel counts (the pair loop runs max-over-lanes times), LDS probes that hit the same few
+// slots and records (broadcast instead of bank conflicts), and in the fitness pass bucket loads that
+// share cache lines.  The cell histogram also yields the marked-cell bitmap (L.wmap) that
+// fill_window and the helpers use.  Uses the LDS pool as scratch (before the window is staged).
+// Returns false (bitmap still produced, scratch copy not written) when the scan is too large for it.
+constexpr int kSortMax = 20000;
+template <bool SSE>
+__device__ __forceinline__ bool sort_points(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
+                                            int n, Lds &L, uint4 *pool, float2 *__restrict__ sp) {
+  const Region r = L.RG;
+  const int ncell = r.rw * r.rh;
+  unsigned *wmap = reinterpret_cast<unsigned *>(L.wpart);
+  unsigned *hist = reinterpret_cast<unsigned *>(pool);                 // ncell + 1 counters (last: outside the window)
+  unsigned *idx = hist + ((ncell + 1 + 3) & ~3);
+  for (int i = threadIdx.x; i <= ncell; i += kBlock) hist[i] = 0u;
+  for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) wmap[i] = 0u;
+  __syncthreads();
+  auto key_of = [&](float2 pt) {
+    float xt, yt;
+    tf_apply_t<SSE>(T0, pt.x, pt.y, xt, yt);
+    if (!finite2(xt, yt)) return ncell;
+    const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const int lx = (int)fx - M.min_bx - r.x0, ly = (int)fy - M.min_by - r.y0;
+    if (lx < 0 || lx >= r.rw || ly < 0 || ly >= r.rh) return ncell;
+    return ly * r.rw + lx;
+  };
+  for (int i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hist[key_of(scan[i])], 1u);
+  __syncthreads();
+  // marked-cell bitmap
+  for (int w = threadIdx.x; w < (ncell + 31) / 32; w += kBlock) {
+    unsigned bits = 0;
+    const int c0 = w * 32, c1 = min(c0 + 32, ncell);
+    for (int c = c0; c < c1; ++c) bits |= (hist[c] != 0u ? 1u : 0u) << (c - c0);
+    wmap[w] = bits;
+  }
+  const bool do_sort = sp != nullptr && n <= kSortMax;
+  if (!do_sort) { __syncthreads(); return false; }
+  // exclusive scan of the ncell + 1 counters
+  const int per = (ncell + 1 + kBlock - 1) / kBlock;
+  const int c0 = min((int)threadIdx.x * per, ncell + 1), c1 = min(c0 + per, ncell + 1);
+  unsigned mine = 0;
+  for (int c = c0; c < c1; ++c) mine += hist[c];
+  unsigned incl = mine;
 #pragma unroll
-    for (int kk = 9; kk >= 0; --kk) {     // descending count
-      starts |= (u64)run << (6 * kk);
-      run += (unsigned)((hist >> (6 * kk)) & 63ull);
-    }
-#pragma nounroll
-    for (int jj = 0; jj < cnt; ++jj) {
-      const unsigned K = (unsigned)(((jj < 16) ? (k_lo >> (4 * jj)) : (k_hi >> (4 * (jj - 16)))) & 15ull);
-      const unsigned pos = (unsigned)((starts >> (6 * K)) & 63ull);
-      starts += 1ull << (6 * K);
-      sp[(size_t)(g0 + (int)pos) * kBlock + threadIdx.x] = scan[(g0 + jj) * kBlock + threadIdx.x];
+  for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if ((int)(threadIdx.x & 63) >= o) incl += t; }
+  if ((threadIdx.x & 63) == 63) L.swave[threadIdx.x >> 6] = (int)incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int w = 0; w < kWaves; ++w) { const int t = L.swave[w]; L.swave[w] = run; run += t; }
+  }
+  __syncthreads();
+  {
+    unsigned run = (unsigned)L.swave[threadIdx.x >> 6] + incl - mine;
+    for (int c = c0; c < c1; ++c) { const unsigned t = hist[c]; hist[c] = run; run += t; }
+  }
+  __syncthreads();
+  // scatter the point numbers; afterwards hist[c] = end of cell c
+  for (int i = threadIdx.x; i < n; i += kBlock) idx[atomicAdd(&hist[key_of(scan[i])], 1u)] = (unsigned)i;
+  __syncthreads();
+  // input order inside a cell (the atomics above arrive in any order): insertion sort of each short segment
+  for (int c = c0; c < c1; ++c) {
+    const int s0 = c ? (int)hist[c - 1] : 0, s1 = (int)hist[c];
+    for (int a = s0 + 1; a < s1; ++a) {
+      const unsigned v = idx[a];
+      int bpos = a - 1;
+      while (bpos >= s0 && idx[bpos] > v) { idx[bpos + 1] = idx[bpos]; --bpos; }
+      idx[bpos + 1] = v;
     }
   }
+  __syncthreads();
+  for (int pos = threadIdx.x; pos < n; pos += kBlock) sp[pos] = scan[idx[pos]];
+  __syncthreads();
+  return true;
 }
 
 // Sum of 12 per-lane values over the 64 lanes of a wave in a fixed order, 86 instructions instead
@@ -1164,37 +1170,33 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     const float2 *pts = scan;
     if (n > 0) {
       compute_region<SSE>(M, L.S.T, scan, n, L);
-      mark_wanted<SSE>(M, L.S.T, scan, n, L);
+      float2 *sp = (sorted && !shared_scan) ? sorted + o0 : nullptr;
+      if (sort_points<SSE>(M, L.S.T, scan, n, L, pool, sp)) pts = sp;
       if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
         const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
         unsigned *gw = wantmap + (size_t)b * (kRegionCells / 32);
         for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) gw[i] = wmap[i];
       }
       fill_window(M, L, pool);
-      const Window W0 = window_of(L.RG, pool);
-      if (sorted && !shared_scan) {
-        float2 *sp = sorted + o0;
-        order_points<SSE, INCL>(M, W0, L.S.T, scan, n, sp);
-        pts = sp;
-      }
       if (allow_helpers) {
         // publish geometry + ordered copy: plain stores, drained by every wave, then one agent release
         if (threadIdx.x == 0) {
           const Region r = L.RG;
           C->region[0] = r.x0; C->region[1] = r.y0; C->region[2] = r.rw; C->region[3] = r.rh;
           C->region[4] = r.cap; C->region[5] = r.nspill;
+          C->use_sorted = (pts != scan) ? 1u : 0u;
         }
         drain_vmem();
         __syncthreads();
         if (threadIdx.x == 0) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
           drain_vmem();
-          st64(&C->ticket, ((u64)1 << 32) | (u64)kUnits);     // epoch 1: open for joining, no unit on offer
+          st64(&C->ticket, (u64)1 << 32);                     // epoch 1: open for joining, nothing to compute (h = 0)
         }
       }
     }
     const Window W = window_of(L.RG, pool);
-    if (threadIdx.x == 0) L.sflag[1] = 0;            // helpers attached (refreshed during every advance)
+    if (threadIdx.x == 0) L.sflag[1] = 0;            // registered helpers (refreshed during every advance)
     unsigned epoch = 1;
     u64 t_eval = 0, t_adv = 0, tt0 = 0, tt1 = 0, t_wait = 0, t_first_shared = 0, t_fit = 0;
     u64 ts1 = 0, ts2 = 0, ts3 = 0, a_pro = 0, a_own = 0, a_wait = 0, a_comb = 0, a_adv = 0, a_n = 0;   // shared derivative passes (diagnostic)
@@ -1205,97 +1207,118 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     while (n > 0 && !fitness_done) {
       if (prof) tt0 = wall_clock64();
       const bool fit_pass = (L.S.phase == PH_DONE);
-      if (threadIdx.x == 0) {
-        L.PP.T = L.S.T; L.PP.cj = L.S.cj; L.PP.sj = L.S.sj; L.PP.ch = L.S.ch; L.PP.sh = L.S.sh;
-        L.PP.kind = fit_pass ? 1 : 0;
-        const int h = allow_helpers >= 1000 ? 1 : (allow_helpers ? L.sflag[1] : 0);   // >= 1000: diagnostic, force shared passes
-        if (allow_helpers) st32(&C->passes, (u32)L.S.evals);
-        // the fitness pass is the longest of a match and runs once: always open it to helpers, also to
-        // those that attach while it is running
-        const int hh = (h == 0 && fit_pass && allow_helpers && allow_helpers < 1000) ? 1 : h;
-        L.sflag[0] = hh;
-        L.own_mask = 0u;
-        if (hh > 0) {                          // open an epoch: pose block, then the ticket
-          const PassPose pp = L.PP;
-          st64(&C->pose[0], ((u64)__float_as_uint(pp.T.s) << 32) | (u64)__float_as_uint(pp.T.c));
-          st64(&C->pose[1], ((u64)__float_as_uint(pp.T.ty) << 32) | (u64)__float_as_uint(pp.T.tx));
-          st64(&C->pose[2], (u64)__double_as_longlong(pp.cj)); st64(&C->pose[3], (u64)__double_as_longlong(pp.sj));
-          st64(&C->pose[4], (u64)__double_as_longlong(pp.ch)); st64(&C->pose[5], (u64)__double_as_longlong(pp.sh));
-          st64(&C->kind, (u64)pp.kind);
-          st32(&C->arrive, 0u);
-          drain_vmem();
-          st64(&C->ticket, (u64)(epoch + 1) << 32);
-        }
-      }
-      __syncthreads();
-      if (prof) ts1 = wall_clock64();
-      const int nhelp = L.sflag[0];
-      const PassPose pp = L.PP;
-      if (nhelp <= 0) {
-        // solo pass: physical wave w computes its own units (w, 0..kSub-1)
-        unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, wave, 0, kSub, L.wpart + wave * 12, kWaves * 12);
-        if (threadIdx.x == 0) L.own_mask = ~0ull;
-      } else {
-        // shared pass: this workgroup's waves and the helpers' waves claim units from the ticket.
-        // Waves beyond the owner's fair share hold back a moment so that helpers get theirs.
-        ++epoch;
-        // the owner's fair share of the units, one per wave, starts at once; its other waves are a
-        // fallback for slow helpers and hold back
-        const int quota = (kUnits + nhelp) / (nhelp + 1);
-        if (wave >= quota) { const u64 w0 = wall_clock64(); while (wall_clock64() - w0 < 600) __builtin_amdgcn_s_sleep(16); }
-        // (a counted loop on purpose: hipcc / ROCm 7.2 miscompiles `for (;;)` + break around
-        // cross-lane work followed by a lane-0 LDS atomic -- tools/repro/ticket2.hip)
-        for (int claims = 0; claims <= kUnits; ++claims) {
-          u64 v = 0;
-          if (lane == 0) v = __hip_atomic_fetch_add(&C->ticket, 1ull, NDT_RLX, NDT_AGENT);
-          v = wave_bcast64(v);
-          const u32 idx = (u32)v;
-          if (idx >= (u32)kUnits) break;
-          unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, (int)(idx % kWaves), (int)(idx / kWaves), (int)(idx / kWaves) + 1,
-                               L.wpart + idx * 12, 0);
-          if (lane == 0) atomicOr(&L.own_mask, 1ull << idx);
-        }
-        __syncthreads();
-        if (prof) ts2 = wall_clock64();
-        // wait for the units the helpers claimed (running waves are computing them)
+      // A pass is run as one or more SEGMENTS of consecutive units.  A derivative pass is one segment:
+      // solo (one walk per wave) or split over the registered helpers.  The fitness pass runs once, can
+      // be long (a poor match walks many rings per point) and usually starts when no helper is free:
+      // solo, its units are handed to the waves one at a time from an LDS counter and the segment is
+      // closed as soon as a helper has registered, so that the rest of the pass is shared.
+      int pass_h = 0, ubeg = 0;
+      bool pose_out = false;                       // thread 0: pose block of this pass is in the control block
+      const u64 t_pass0 = wall_clock64();
+      for (int seg = 0; seg <= kUnits && ubeg < kUnits; ++seg) {
         if (threadIdx.x == 0) {
-          const u32 need = (u32)(kUnits - __builtin_popcountll(L.own_mask));
-          int bad = 0; unsigned polls = 0;
-          const u64 w0 = wall_clock64();
-          while (ld32(&C->arrive) < need) {
-            if (watchdog(hdr, t_start, polls)) { bad = 1; break; }
-            __builtin_amdgcn_s_sleep(8);
+          if (seg == 0) {
+            L.PP.T = L.S.T; L.PP.cj = L.S.cj; L.PP.sj = L.S.sj; L.PP.ch = L.S.ch; L.PP.sh = L.S.sh;
+            L.PP.kind = fit_pass ? 1 : 0;
+            if (allow_helpers) { st32(&C->passes, (u32)L.S.evals); if (fit_pass) st32(&C->phase, 1u); }
+          } else if (allow_helpers) {
+            L.sflag[1] = (int)ld32(&C->ready);
           }
-          t_wait += wall_clock64() - w0;
-          if (n_shared == 0) t_first_shared = w0 - t_start;
-          n_shared += 1; n_helped += need;
-          L.sflag[2] = bad;
+          const int h = allow_helpers ? min(L.sflag[1], kMaxHelpers) : 0;
+          L.sflag[0] = h;
+          L.jnext = 0; L.stop = 0;
+          if (h > 0) {                          // open an epoch: pose block, then the epoch word
+            const PassPose pp = L.PP;
+            if (!pose_out) {
+              pose_out = true;
+              st64(&C->pose[0], ((u64)__float_as_uint(pp.T.s) << 32) | (u64)__float_as_uint(pp.T.c));
+              st64(&C->pose[1], ((u64)__float_as_uint(pp.T.ty) << 32) | (u64)__float_as_uint(pp.T.tx));
+              st64(&C->pose[2], (u64)__double_as_longlong(pp.cj)); st64(&C->pose[3], (u64)__double_as_longlong(pp.sj));
+              st64(&C->pose[4], (u64)__double_as_longlong(pp.ch)); st64(&C->pose[5], (u64)__double_as_longlong(pp.sh));
+            }
+            st32(&C->arrive, 0u);
+            drain_vmem();
+            st64(&C->ticket, ((u64)(epoch + 1) << 32) | ((u64)pp.kind << 24) | ((u64)h << 16) | ((u64)kUnits << 8) | (u64)ubeg);
+          }
         }
         __syncthreads();
-        if (prof) ts3 = wall_clock64();
-        if (L.sflag[2]) { aborted = true; break; }
+        if (prof) ts1 = wall_clock64();
+        const int nhelp = L.sflag[0];
+        const PassPose pp = L.PP;
+        int uend = kUnits;
+        if (nhelp <= 0 && !fit_pass) {
+          // solo derivative pass: wave w computes its own units (w, 0..kSub-1) in one walk
+          unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, wave, 0, kSub, L.wpart + wave * 12, kWaves * 12);
+        } else {
+          // this workgroup's units ubeg + j*(nhelp+1), j = 0, 1, ... handed to its waves from an LDS counter
+          const bool watch = fit_pass && nhelp == 0 && allow_helpers;
+          for (int it = 0; it <= kUnits; ++it) {             // counted (tools/repro/ticket2.hip)
+            if (watch && L.stop) break;
+            int j = 0;
+            if (lane == 0) j = atomicAdd(&L.jnext, 1);
+            j = __builtin_amdgcn_readfirstlane(j);
+            const int u = ubeg + j * (nhelp + 1);
+            if (u >= kUnits) break;
+            unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, u % kWaves, u / kWaves, u / kWaves + 1, L.wpart + u * 12, 0);
+            if (watch && wave == kWaves - 1 && lane == 0) {
+              // one wave looks for a registered helper between its units; a pass that has been running
+              // for 100 us with more than half of it to go asks for one
+              if (ld32(&C->ready) > 0u) L.stop = 1;
+              else if (u < kUnits / 2 && wall_clock64() - t_pass0 > 10000) st32(&C->passes, 150u);
+            }
+          }
+          if (watch) {                                       // units [ubeg, ubeg + claimed) are done
+            __syncthreads();
+            uend = min(kUnits, ubeg + L.jnext);
+          }
+        }
+        if (nhelp > 0) {
+          ++epoch;
+          pass_h = nhelp;
+          __syncthreads();
+          if (prof) ts2 = wall_clock64();
+          // wait for the helpers' units (every counted helper is polling the epoch word or computing)
+          if (threadIdx.x == 0) {
+            const int total = kUnits - ubeg;
+            const int mine = (total + nhelp) / (nhelp + 1);
+            const u32 need = (u32)(total - mine);
+            int bad = 0; unsigned polls = 0;
+            const u64 w0 = wall_clock64();
+            while (ld32(&C->arrive) < need) {
+              if (watchdog(hdr, t_start, polls)) { bad = 1; break; }
+              __builtin_amdgcn_s_sleep(2);
+            }
+            t_wait += wall_clock64() - w0;
+            if (n_shared == 0) t_first_shared = w0 - t_start;
+            n_shared += 1; n_helped += need;
+            L.sflag[2] = bad;
+          }
+          __syncthreads();
+          if (prof) ts3 = wall_clock64();
+          if (L.sflag[2]) { aborted = true; break; }
+          // helpers' totals of this segment: one load per lane, in flight together
+          if (threadIdx.x < (kUnits - ubeg) * 12) {
+            const int u = ubeg + threadIdx.x / 12;
+            if ((u - ubeg) % (nhelp + 1) != 0)
+              L.wpart[ubeg * 12 + threadIdx.x] = __longlong_as_double((long long)ld64(&mytot[ubeg * 12 + threadIdx.x]));
+          }
+        }
+        __syncthreads();
+        ubeg = uend;
       }
-      __syncthreads();
-      // pass total = sum of the unit totals in unit order (own units from LDS, helpers' from HBM)
-      {
-        const unsigned long long mine = L.own_mask;
-        if (mine != ~0ull && threadIdx.x < kUnits * 12) {     // helpers' totals: one load per lane, in flight together
-          const int v = threadIdx.x / 12;
-          if (!((mine >> v) & 1ull)) L.wpart[threadIdx.x] = __longlong_as_double((long long)ld64(&mytot[threadIdx.x]));
-        }
-        __syncthreads();
-        if (threadIdx.x < 12) {
-          double s = 0.0;
-          for (int v = 0; v < kUnits; ++v) s += L.wpart[v * 12 + threadIdx.x];
-          L.tot[threadIdx.x] = s;
-        }
+      if (aborted) break;
+      // pass total = sum of the unit totals in unit order
+      if (threadIdx.x < 12) {
+        double sum = 0.0;
+        for (int v = 0; v < kUnits; ++v) sum += L.wpart[v * 12 + threadIdx.x];
+        L.tot[threadIdx.x] = sum;
       }
       __syncthreads();
       if (prof) { tt1 = wall_clock64(); t_eval += tt1 - tt0; if (fit_pass) t_fit = tt1 - tt0; }
       if (!fit_pass) {
         if (threadIdx.x == 0) advance(L.S, P, M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
-        // meanwhile another wave fetches the number of attached helpers for the next pass
-        if (threadIdx.x == 64 && allow_helpers && allow_helpers < 1000) L.sflag[1] = (int)rd32_fresh(&C->helpers);
+        // meanwhile another wave fetches the number of registered helpers for the next pass
+        if (threadIdx.x == 64 && allow_helpers) L.sflag[1] = (int)rd32_fresh(&C->ready);
       } else {
         fitness_done = true;
       }
@@ -1303,7 +1326,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       if (prof) {
         const u64 te = wall_clock64();
         t_adv += te - tt1;
-        if (nhelp > 0 && !fit_pass) { a_pro += ts1 - tt0; a_own += ts2 - ts1; a_wait += ts3 - ts2; a_comb += tt1 - ts3; a_adv += te - tt1; a_n += 1; }
+        if (pass_h > 0 && !fit_pass) { a_pro += ts1 - tt0; a_own += ts2 - ts1; a_wait += ts3 - ts2; a_comb += tt1 - ts3; a_adv += te - tt1; a_n += 1; }
       }
     }
     // ---- result record; close the scan ----
@@ -1342,7 +1365,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
   }
 
   // ============================================ helper ============================================
-  if (!allow_helpers || aborted || allow_helpers >= 1000) return;
+  if (!allow_helpers || aborted) return;
   u64 idle_ticks = 400;
   for (unsigned rounds = 0; rounds < 0x40000000u; ++rounds) {
     // ---- find an unfinished scan that still has room for a helper ----
@@ -1391,12 +1414,12 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     const int vb = L.sflag[3];
     if (vb == -2) break;
     if (vb < 0) continue;
-    // ---- attached to scan vb: stage its window, then every wave claims units until the scan is done ----
+    // ---- attached to scan vb: stage its window, register, then serve its epochs until it is done ----
     ScanCtl *C = ctl + vb;
     const u64 o0 = shared_scan ? offsets[0] : offsets[vb];
     const u64 o1 = shared_scan ? offsets[1] : offsets[vb + 1];
     const int n = (int)(o1 - o0);
-    const float2 *pts = (sorted && !shared_scan) ? (sorted + o0) : (reinterpret_cast<const float2 *>(scans) + o0);
+    if (threadIdx.x == 0) L.sflag[1] = (int)C->use_sorted;
     if (threadIdx.x == 0) {
       Region r; r.x0 = C->region[0]; r.y0 = C->region[1]; r.rw = C->region[2]; r.rh = C->region[3];
       r.cap = C->region[4]; r.nspill = C->region[5];
@@ -1407,91 +1430,68 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       const unsigned *gw = wantmap + (size_t)vb * (kRegionCells / 32);
       for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) wmap[i] = gw[i];
     }
+    if (threadIdx.x == 0) L.sflag[2] = (int)ld32(&C->phase);
     __syncthreads();
-    fill_window(M, L, pool);
+    const float2 *pts = L.sflag[1] ? (sorted + o0) : (reinterpret_cast<const float2 *>(scans) + o0);
+    if (L.sflag[2] == 0) fill_window(M, L, pool);          // a scan in its fitness pass needs no window
     const Window W = window_of(L.RG, pool);
     if (prof && threadIdx.x == 0 && prof[8 * vb + 5] == 0) prof[8 * vb + 5] = wall_clock64() - t_start;
     u64 *vtot = utot + (size_t)vb * kUnits * 12;
-    if (threadIdx.x == 0) L.hep = 0u;
+    // register: from now on this workgroup does nothing but watch the scan's epoch word
+    if (threadIdx.x == 0) L.hrank = (int)__hip_atomic_fetch_add(&C->ready, 1u, NDT_RLX, NDT_AGENT);
     __syncthreads();
-    {
-      unsigned my_ep = 0, polls = 0;
-      PassPose pp; pp.kind = 0; pp.cj = pp.sj = pp.ch = pp.sh = 0.0; pp.T.c = pp.T.s = pp.T.tx = pp.T.ty = 0.f;
-      for (unsigned turns = 0; turns < 0x40000000u; ++turns) {       // counted, see the owner's claim loop
-        u64 v = 0;
-        if (lane == 0) v = __hip_atomic_fetch_add(&C->ticket, 1ull, NDT_RLX, NDT_AGENT);
-        v = wave_bcast64(v);
-        const u32 ep = (u32)(v >> 32), idx = (u32)v;
-        if (ep == kEpochDone) break;
-        if (idx >= (u32)kUnits) {
-          // nothing on offer: wait for the next epoch (or the end of the scan).  Wave 0 polls the
-          // ticket line, copies the new pose block to LDS and raises L.hep; the other waves watch
-          // L.hep, so one load per helper workgroup is in flight on the owner's line.
-          int bad = 0;
-          if (wave == 0) {
-            u32 nep = ep;
-            if (lane == 0) {
-              while ((nep = (u32)(ld64(&C->ticket) >> 32)) == ep) {
-                if (watchdog(hdr, t_start, polls)) { bad = 1; break; }
-                __builtin_amdgcn_s_sleep(2);
-              }
-            }
-            nep = __builtin_amdgcn_readfirstlane(nep);
-            bad = __builtin_amdgcn_readfirstlane(bad);
-            if (!bad && nep == kEpochDone) {
-              if (lane == 0) __hip_atomic_store(&L.hep, nep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else if (!bad) {
-              u64 w = 0;
-              if (lane < 7) w = ld64(lane < 6 ? &C->pose[lane] : &C->kind);
-              if (lane < 7) L.hpose[lane] = w;
-              __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the pose words are in LDS
-              // the pose block belongs to epoch nep only if the ticket still shows nep afterwards
-              u32 chk = nep;
-              if (lane == 0) chk = (u32)(ld64(&C->ticket) >> 32);
-              chk = __builtin_amdgcn_readfirstlane(chk);
-              if (lane == 0 && chk == nep) __hip_atomic_store(&L.hep, nep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-          } else {
-            if (lane == 0) {
-              const u64 w0 = wall_clock64();
-              for (int it = 0; it < (1 << 24); ++it) {       // counted: ends by the clock long before
-                const u32 hs = __hip_atomic_load(&L.hep, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (hs == ep + 1u || hs == kEpochDone) break;
-                if (wall_clock64() - w0 > 1000) break;       // 10 us: look at the ticket ourselves again
-                __builtin_amdgcn_s_sleep(1);
-              }
-            }
-          }
-          if (bad) break;
-          continue;
-        }
-        if (ep != my_ep) {                                   // first unit of a new epoch: its pose block
-          u64 w = 0;
-          const bool staged = __hip_atomic_load(&L.hep, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == ep;
-          if (staged) { if (lane < 7) w = L.hpose[lane]; }
-          else {
-            // this wave is first to see the epoch (it holds a unit of it, so the block is stable): stage it
-            if (lane < 7) { w = ld64(lane < 6 ? &C->pose[lane] : &C->kind); L.hpose[lane] = w; }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            if (lane == 0) __hip_atomic_store(&L.hep, ep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-          }
-          const u64 w0 = __shfl(w, 0), w1 = __shfl(w, 1), w2 = __shfl(w, 2), w3 = __shfl(w, 3), w4 = __shfl(w, 4),
-                    w5 = __shfl(w, 5), w6 = __shfl(w, 6);
-          pp.T.c = __uint_as_float((u32)w0); pp.T.s = __uint_as_float((u32)(w0 >> 32));
-          pp.T.tx = __uint_as_float((u32)w1); pp.T.ty = __uint_as_float((u32)(w1 >> 32));
-          pp.cj = __longlong_as_double((long long)w2); pp.sj = __longlong_as_double((long long)w3);
-          pp.ch = __longlong_as_double((long long)w4); pp.sh = __longlong_as_double((long long)w5);
-          pp.kind = (int)w6;
-          my_ep = ep;
-        }
-        double *wt = L.wtmp + wave * 12;
-        unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, (int)(idx % kWaves), (int)(idx / kWaves), (int)(idx / kWaves) + 1, wt, 0);
-        if (lane < 12) st64(&vtot[idx * 12 + lane], (u64)__double_as_longlong(wt[lane]));
-        drain_vmem();                                        // the whole wave: its stores have landed
+    const int rank = L.hrank;
+    u32 last_ep = 0;
+    for (unsigned turns = 0; turns < 0x40000000u; ++turns) {         // counted (tools/repro/ticket2.hip)
+      if (wave == 0) {
+        // wave 0 polls the epoch word (one load in flight per helper workgroup on the owner's line)
+        u64 word = 0;
         if (lane == 0) {
-          __hip_atomic_fetch_add(&C->arrive, 1u, NDT_RLX, NDT_AGENT);
+          unsigned polls = 0;
+          for (unsigned it = 0; it < 0x40000000u; ++it) {
+            word = ld64(&C->ticket);
+            if ((u32)(word >> 32) != last_ep && (u32)(word >> 32) != 0u) break;
+            if (watchdog(hdr, t_start, polls)) { word = (u64)kEpochDone << 32; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
         }
+        word = wave_bcast64(word);
+        const int h = (int)((word >> 16) & 0xFFu);
+        if ((u32)(word >> 32) != kEpochDone && rank < h && lane < 6) L.hpose[lane] = ld64(&C->pose[lane]);   // stable: this helper is counted in
+        if (lane == 0) { L.hword = word; L.jnext = 0; }
       }
+      __syncthreads();
+      const u64 word = L.hword;
+      const u32 ep = (u32)(word >> 32);
+      if (ep == kEpochDone) break;
+      last_ep = ep;
+      const int h = (int)((word >> 16) & 0xFFu), ubeg = (int)(word & 0xFFu), uend = (int)((word >> 8) & 0xFFu);
+      int done_units = 0;
+      if (rank < h) {
+        PassPose pp;
+        const u64 w0 = L.hpose[0], w1 = L.hpose[1];
+        pp.T.c = __uint_as_float((u32)w0); pp.T.s = __uint_as_float((u32)(w0 >> 32));
+        pp.T.tx = __uint_as_float((u32)w1); pp.T.ty = __uint_as_float((u32)(w1 >> 32));
+        pp.cj = __longlong_as_double((long long)L.hpose[2]); pp.sj = __longlong_as_double((long long)L.hpose[3]);
+        pp.ch = __longlong_as_double((long long)L.hpose[4]); pp.sh = __longlong_as_double((long long)L.hpose[5]);
+        pp.kind = (int)((word >> 24) & 0xFFu);
+        double *wt = L.wtmp + wave * 12;
+        for (int it = 0; it <= kUnits; ++it) {               // this workgroup's units, handed out from an LDS counter
+          int j = 0;
+          if (lane == 0) j = atomicAdd(&L.jnext, 1);
+          j = __builtin_amdgcn_readfirstlane(j);
+          const int u = ubeg + (rank + 1) + j * (h + 1);
+          if (u >= uend) break;
+          unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, u % kWaves, u / kWaves, u / kWaves + 1, wt, 0);
+          if (lane < 12) st64(&vtot[u * 12 + lane], (u64)__double_as_longlong(wt[lane]));
+        }
+        drain_vmem();                                        // the whole wave: its stores have landed
+        const int total = uend - ubeg;
+        done_units = (total - (rank + 1) + h) / (h + 1);     // units ubeg + rank+1 + j*(h+1) below uend
+        if (done_units < 0) done_units = 0;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0 && done_units > 0) __hip_atomic_fetch_add(&C->arrive, (u32)done_units, NDT_RLX, NDT_AGENT);
     }
   }
 }
@@ -2019,6 +2019,8 @@ int ndt_ctx_create(int device, ndt_ctx **out) {
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
     c->helpers = getenv("NDT_NO_HELPERS") ? 0 : kMaxHelpers;
     if (getenv("NDT_MAX_HELPERS")) c->helpers = atoi(getenv("NDT_MAX_HELPERS"));
+    if (c->helpers > kMaxHelpers) c->helpers = kMaxHelpers;
+    if (c->helpers < 0) c->helpers = 0;
     if (getenv("NDT_GRID")) c->num_cus = atoi(getenv("NDT_GRID"));
   }
   *out = c;
