@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libndt_mi355x.so")
+LIB_PATH = os.environ.get("NDT_LIB_PATH") or os.path.join(_HERE, "libndt_mi355x.so")   # override: diagnostic builds
 _LIB = None
 
 

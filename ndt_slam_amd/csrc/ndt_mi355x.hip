@@ -265,6 +265,10 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
   const unsigned short *srow = W.slot + (cly - 1) * R.rw + (clx - 1);
   unsigned mask = 0;
   float lowx = INFINITY;                       // -inf <=> one of the nine voxels is occupied but not resident
+#ifdef NDT_EXP_NO_PROBES
+  if (xt == 12345.678f) A.e += (double)srow[0];  // experiment: no LDS probes at all
+  return;
+#endif
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -273,6 +277,9 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
       lowx = fminf(lowx, cc.x);
       mask |= in_radius<INCL>(M.r2, xt, yt, cc) << (r * 3 + q);
     }
+#ifdef NDT_EXP_NO_CELLS
+  mask = 0;                                     // experiment: probes only
+#endif
   if (inwin & (lowx != -INFINITY)) {
     if (!mask) return;
     A.pairs += __builtin_popcount(mask);
@@ -880,72 +887,116 @@ __device__ __forceinline__ void compute_region(const MapView &M, const Tf32 &T0,
 // the content depends only on the map, the geometry and the bitmap.  Slot values: < cap a resident
 // record; cap = voxel outside the search set (centroid +inf); cap + 1 = occupied voxel without an
 // LDS record (centroid -inf).  Sets L.RG.nspill = occupied voxels left without a record.
+// Cells are walked 1024 at a time with consecutive lanes on consecutive cells (coalesced centroid
+// and record reads); the row-major numbering comes from wave ballots kept in LDS.
 __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool) {
   const Region r = L.RG;
   const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
   unsigned short *slot = reinterpret_cast<unsigned short *>(pool);
   CellEntry *ent = reinterpret_cast<CellEntry *>(reinterpret_cast<char *>(pool) + ((r.rw * r.rh * 2 + 15) / 16) * 16);
   const int ncell = r.rw * r.rh;
-  const int per = (ncell + kBlock - 1) / kBlock;
-  const int c0 = threadIdx.x * per, c1 = min(c0 + per, ncell);
-  auto wanted = [&](int lx, int ly) {
-    unsigned any = 0;
-    for (int dy = -2; dy <= 2; ++dy) {
-      const int yy = ly + dy;
-      if (yy < 0 || yy >= r.rh) continue;
-      const int xa = max(lx - 2, 0), xb = min(lx + 2, r.rw - 1);
-      for (int xx = xa; xx <= xb; ++xx) { const int bit = yy * r.rw + xx; any |= wmap[bit >> 5] >> (bit & 31); }
-    }
-    return (any & 1u) != 0u;
+  const int rounds = (ncell + kBlock - 1) / kBlock;          // <= kRegionCells / kBlock = 16
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u64 *keepw = reinterpret_cast<u64 *>(L.wpart) + 256;        // [rounds][kWaves] ballots (wmap uses the first 2 KiB)
+  u64 *occw = keepw + 256;
+  int *base = reinterpret_cast<int *>(L.wtmp);                // [256] exclusive prefix of the kept counts
+  // any marked cell in columns [lx-2, lx+2] of row yy
+  auto row_marked = [&](int yy, int lx) {
+    const int xa = max(lx - 2, 0), xb = min(lx + 2, r.rw - 1);
+    const int b0 = yy * r.rw + xa, len = xb - xa + 1;
+    const unsigned lo = wmap[b0 >> 5], hi = wmap[min((b0 >> 5) + 1, kRegionCells / 32 - 1)];
+    const u64 both = ((u64)hi << 32) | lo;
+    return ((both >> (b0 & 31)) & ((1ull << len) - 1ull)) != 0ull;
   };
-  int mine = 0, skipped = 0;
-  unsigned keep = 0;                            // bit j: cell c0 + j gets a record (per <= 32)
-  for (int c = c0; c < c1; ++c) {
-    const int ly = c / r.rw, lx = c - ly * r.rw;
-    const float2 cc = M.cent[(size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2)];
-    if (cc.x < INFINITY) {                      // +inf marks voxels outside the search set
-      if (wanted(lx, ly)) { ++mine; keep |= 1u << (c - c0); } else ++skipped;
+  for (int j0 = 0; j0 < rounds; j0 += 4) {                   // four rounds' centroid loads in flight together
+    float cx[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = (j0 + u) * kBlock + threadIdx.x;
+      cx[u] = INFINITY;
+      if (c < ncell) { const int ly = c / r.rw, lx = c - ly * r.rw; cx[u] = M.cent[(size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2)].x; }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u, c = j * kBlock + threadIdx.x;
+      if (j >= rounds) break;
+      const bool occ = cx[u] < INFINITY;        // +inf marks voxels outside the search set
+      bool keep = false;
+      if (occ) {
+        const int ly = c / r.rw, lx = c - ly * r.rw;
+        for (int dy = -2; dy <= 2 && !keep; ++dy) {
+          const int yy = ly + dy;
+          if (yy >= 0 && yy < r.rh) keep = row_marked(yy, lx);
+        }
+      }
+      const u64 kb = __ballot(keep), ob = __ballot(occ);
+      if (lane == 0) { keepw[j * kWaves + wave] = kb; occw[j * kWaves + wave] = ob; }
     }
   }
-  int incl = mine;                              // exclusive prefix of `mine` over the workgroup
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if ((int)(threadIdx.x & 63) >= o) incl += t; }
-  if ((threadIdx.x & 63) == 63) L.swave[threadIdx.x >> 6] = incl;
-  if (threadIdx.x == 0) L.sbox[0] = 0;
   __syncthreads();
-  if (skipped) atomicAdd(&L.sbox[0], skipped);
-  if (threadIdx.x == 0) {
-    int run = 0;
-    for (int w = 0; w < kWaves; ++w) { const int t = L.swave[w]; L.swave[w] = run; run += t; }
-    L.swave[kWaves] = run;
+  // exclusive prefix of the kept counts over the rounds * kWaves ballot words (cell order)
+  const int nword = rounds * kWaves;                           // <= 256
+  if (threadIdx.x < 256) {
+    const int mine = (int)threadIdx.x < nword ? __builtin_popcountll(keepw[threadIdx.x]) : 0;
+    const int skip = (int)threadIdx.x < nword ? __builtin_popcountll(occw[threadIdx.x] & ~keepw[threadIdx.x]) : 0;
+    int incl = mine, sk = skip;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o); if (lane >= o) incl += t;
+      sk += __shfl_xor(sk, o);
+    }
+    base[threadIdx.x] = incl - mine;
+    if (lane == 63) { L.swave[wave] = incl; L.sbox[wave] = sk; }
   }
   __syncthreads();
-  int next = L.swave[threadIdx.x >> 6] + incl - mine;
+  if (threadIdx.x < 256) {
+    int add = 0;
+    for (int w = 0; w < wave; ++w) add += L.swave[w];
+    base[threadIdx.x] += add;
+  }
   if (threadIdx.x == 0) {
+    const int kept = L.swave[0] + L.swave[1] + L.swave[2] + L.swave[3];
+    const int skipped = L.sbox[0] + L.sbox[1] + L.sbox[2] + L.sbox[3];
     CellEntry z; z.cent = make_float2(INFINITY, INFINITY); z.mx = z.my = z.i00 = z.i01 = z.i11 = 0.0;
     ent[r.cap] = z;                             // voxels outside the search set
     z.cent = make_float2(-INFINITY, -INFINITY);
     ent[r.cap + 1] = z;                         // occupied voxels without an LDS record
-    L.RG.nspill = L.sbox[0] + (L.swave[kWaves] > r.cap ? L.swave[kWaves] - r.cap : 0);
+    L.RG.nspill = skipped + (kept > r.cap ? kept - r.cap : 0);
   }
-  for (int c = c0; c < c1; ++c) {
-    const int ly = c / r.rw, lx = c - ly * r.rw;
-    const size_t pg = (size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2);
-    const float2 cc = M.cent[pg];
-    unsigned sl = (unsigned)r.cap;
-    if (cc.x < INFINITY) {
-      sl = (unsigned)r.cap + 1u;
-      if ((keep >> (c - c0)) & 1u) {
-        if (next < r.cap) {
-          const double *rec = M.rec + pg * 8;
-          CellEntry E; E.cent = cc; E.mx = rec[0]; E.my = rec[1]; E.i00 = rec[2]; E.i01 = rec[3]; E.i11 = rec[4];
-          ent[next] = E;
-          sl = (unsigned)next;
+  __syncthreads();
+  for (int j0 = 0; j0 < rounds; j0 += 4) {                   // four rounds' record loads in flight together
+    int nx[4]; float2 cc[4]; double2 ra[4], rb[4]; double rc[4]; unsigned sl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u, c = j * kBlock + threadIdx.x;
+      nx[u] = -1; sl[u] = (unsigned)r.cap;
+      if (j < rounds && c < ncell) {
+        const u64 kb = keepw[j * kWaves + wave], ob = occw[j * kWaves + wave];
+        if ((ob >> lane) & 1ull) {
+          sl[u] = (unsigned)r.cap + 1u;
+          if ((kb >> lane) & 1ull) {
+            const int next = base[j * kWaves + wave] + __builtin_popcountll(kb & ((1ull << lane) - 1ull));
+            if (next < r.cap) {
+              const int ly = c / r.rw, lx = c - ly * r.rw;
+              const size_t pg = (size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2);
+              const double *rec = M.rec + pg * 8;
+              cc[u] = M.cent[pg];
+              ra[u] = *reinterpret_cast<const double2 *>(rec); rb[u] = *reinterpret_cast<const double2 *>(rec + 2); rc[u] = rec[4];
+              nx[u] = next; sl[u] = (unsigned)next;
+            }
+          }
         }
-        ++next;
       }
     }
-    slot[c] = (unsigned short)sl;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u, c = j * kBlock + threadIdx.x;
+      if (nx[u] >= 0) {
+        CellEntry E; E.cent = cc[u]; E.mx = ra[u].x; E.my = ra[u].y; E.i00 = rb[u].x; E.i01 = rb[u].y; E.i11 = rc[u];
+        ent[nx[u]] = E;
+      }
+      if (j < rounds && c < ncell) slot[c] = (unsigned short)sl[u];
+    }
   }
   __syncthreads();
 }
@@ -959,7 +1010,7 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
 // share cache lines.  The cell histogram also yields the marked-cell bitmap (L.wmap) that
 // fill_window and the helpers use.  Uses the LDS pool as scratch (before the window is staged).
 // Returns false (bitmap still produced, scratch copy not written) when the scan is too large for it.
-constexpr int kSortMax = 20000;
+constexpr int kSortMax = 20000;             // LDS room for one word per point; point numbers < 2^15
 template <bool SSE>
 __device__ __forceinline__ bool sort_points(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
                                             int n, Lds &L, uint4 *pool, float2 *__restrict__ sp) {
@@ -981,7 +1032,13 @@ __device__ __forceinline__ bool sort_points(const MapView &M, const Tf32 &T0, co
     if (lx < 0 || lx >= r.rw || ly < 0 || ly >= r.rh) return ncell;
     return ly * r.rw + lx;
   };
-  for (int i = threadIdx.x; i < n; i += kBlock) atomicAdd(&hist[key_of(scan[i])], 1u);
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * kBlock) {      // four loads in flight
+    float2 pt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pt[u] = scan[min(i0 + u * kBlock, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i0 + u * kBlock < n) atomicAdd(&hist[key_of(pt[u])], 1u);
+  }
   __syncthreads();
   // marked-cell bitmap
   for (int w = threadIdx.x; w < (ncell + 31) / 32; w += kBlock) {
@@ -1012,21 +1069,41 @@ __device__ __forceinline__ bool sort_points(const MapView &M, const Tf32 &T0, co
     for (int c = c0; c < c1; ++c) { const unsigned t = hist[c]; hist[c] = run; run += t; }
   }
   __syncthreads();
-  // scatter the point numbers; afterwards hist[c] = end of cell c
-  for (int i = threadIdx.x; i < n; i += kBlock) idx[atomicAdd(&hist[key_of(scan[i])], 1u)] = (unsigned)i;
-  __syncthreads();
-  // input order inside a cell (the atomics above arrive in any order): insertion sort of each short segment
-  for (int c = c0; c < c1; ++c) {
-    const int s0 = c ? (int)hist[c - 1] : 0, s1 = (int)hist[c];
-    for (int a = s0 + 1; a < s1; ++a) {
-      const unsigned v = idx[a];
-      int bpos = a - 1;
-      while (bpos >= s0 && idx[bpos] > v) { idx[bpos + 1] = idx[bpos]; --bpos; }
-      idx[bpos + 1] = v;
+  // scatter (cell, point number) packed in one word; afterwards hist[c] = end of cell c
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * kBlock) {
+    float2 pt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pt[u] = scan[min(i0 + u * kBlock, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + u * kBlock >= n) break;
+      const int key = key_of(pt[u]);
+      idx[atomicAdd(&hist[key], 1u)] = ((unsigned)key << 15) | (unsigned)(i0 + u * kBlock);
     }
   }
   __syncthreads();
-  for (int pos = threadIdx.x; pos < n; pos += kBlock) sp[pos] = scan[idx[pos]];
+  // input order inside a cell (the atomics above arrive in any order): every entry finds its rank among
+  // the entries of its cell -- neighbouring lanes read the same short segment -- and its point goes
+  // straight to that place of the scratch copy
+  for (int p0 = threadIdx.x; p0 < n; p0 += 4 * kBlock) {
+    int dstpos[4]; float2 pt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pp = p0 + u * kBlock;
+      dstpos[u] = -1;
+      if (pp < n) {
+        const unsigned v = idx[pp];
+        const int key = (int)(v >> 15);
+        const int s0 = key ? (int)hist[key - 1] : 0, s1 = (int)hist[key];
+        int rank = 0;
+        for (int a = s0; a < s1; ++a) rank += idx[a] < v ? 1 : 0;
+        dstpos[u] = s0 + rank;
+        pt[u] = scan[v & 0x7FFFu];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (dstpos[u] >= 0) sp[dstpos[u]] = pt[u];
+  }
   __syncthreads();
   return true;
 }
@@ -1067,10 +1144,22 @@ __device__ __forceinline__ void wave_reduce12(const double (&a)[12], int lane, d
 // This routine computes the consecutive runs [q0, q1) of virtual wave w in ONE walk over k (the
 // point prefetch keeps running across run boundaries) and leaves the 12 sums of run q at
 // dst[(q - q0) * dst_stride .. +12) (LDS).
+// wave-uniform values read from LDS land in VGPRs; these move them to SGPRs (the pass loop is short of VGPRs)
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uniform_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
 template <bool SSE, bool INCL>
 __device__ __forceinline__ void unit_sums(const MapView &M, const Window &W, const double *__restrict__ etab,
-                                          const PassPose &pp, const float2 *__restrict__ pts, int n, int w,
+                                          const PassPose &pp_in, const float2 *__restrict__ pts, int n, int w,
                                           int q0, int q1, double *__restrict__ dst, int dst_stride) {
+  PassPose pp;
+  pp.T.c = uniform_f(pp_in.T.c); pp.T.s = uniform_f(pp_in.T.s); pp.T.tx = uniform_f(pp_in.T.tx); pp.T.ty = uniform_f(pp_in.T.ty);
+  pp.cj = uniform_d(pp_in.cj); pp.sj = uniform_d(pp_in.sj); pp.ch = uniform_d(pp_in.ch); pp.sh = uniform_d(pp_in.sh);
+  pp.kind = __builtin_amdgcn_readfirstlane(pp_in.kind);
   const int lane = threadIdx.x & 63, last = n - 1;
   const int per_lane = (n + kBlock - 1) / kBlock;          // points of the longest lane
   const int run = (per_lane + kSub - 1) / kSub;
@@ -1169,15 +1258,24 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     __syncthreads();
     const float2 *pts = scan;
     if (n > 0) {
+      const u64 q0 = wall_clock64();
       compute_region<SSE>(M, L.S.T, scan, n, L);
+      const u64 q1 = wall_clock64();
       float2 *sp = (sorted && !shared_scan) ? sorted + o0 : nullptr;
       if (sort_points<SSE>(M, L.S.T, scan, n, L, pool, sp)) pts = sp;
+      const u64 q2 = wall_clock64();
       if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
         const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
         unsigned *gw = wantmap + (size_t)b * (kRegionCells / 32);
         for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) gw[i] = wmap[i];
       }
       fill_window(M, L, pool);
+      const u64 q3 = wall_clock64();
+      if (prof && threadIdx.x == 0) {
+        const u64 q4 = wall_clock64();
+        prof[8 * (size_t)B + 8 * (size_t)b + 6] = ((q1 - q0) << 32) | ((q2 - q1) & 0xFFFFFFFFull);
+        prof[8 * (size_t)B + 8 * (size_t)b + 7] = ((q3 - q2) << 32) | ((q4 - q3) & 0xFFFFFFFFull);
+      }
       if (allow_helpers) {
         // publish geometry + ordered copy: plain stores, drained by every wave, then one agent release
         if (threadIdx.x == 0) {
