@@ -1665,11 +1665,17 @@ __global__ void __launch_bounds__(256)
 map_minmax_kernel(const float *__restrict__ xy, size_t stride, size_t n, unsigned *__restrict__ bounds) {
   __shared__ float sh[4][4];
   float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float2 p = load_pt(xy, stride, i);
-    if (!finite2(p.x, p.y)) continue;
-    mnx = fminf(mnx, p.x); mxx = fmaxf(mxx, p.x);
-    mny = fminf(mny, p.y); mxy = fmaxf(mxy, p.y);
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i0 < n; i0 += 16 * step) {   // 16 loads in flight
+    float2 p[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const size_t i = i0 + u * step; p[u] = load_pt(xy, stride, i < n ? i : i0); }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (!finite2(p[u].x, p[u].y)) continue;
+      mnx = fminf(mnx, p[u].x); mxx = fmaxf(mxx, p[u].x);
+      mny = fminf(mny, p[u].y); mxy = fmaxf(mxy, p[u].y);
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -1727,6 +1733,7 @@ map_count_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims
 
 // exclusive scan of count[0..ng) into start[0..ng], three small kernels
 constexpr int kScanBlock = 256, kScanPer = 8, kScanTile = kScanBlock * kScanPer;
+constexpr int kBigVoxel = 16;        // voxels with more points are handled by a whole wave (order, statistics)
 
 __global__ void __launch_bounds__(kScanBlock)
 scan_tile_sums_kernel(const int *__restrict__ in, size_t n, int *__restrict__ tile_sum) {
@@ -1771,7 +1778,8 @@ scan_tile_offsets_kernel(int *__restrict__ tile_sum, int ntiles, int *__restrict
 
 __global__ void __launch_bounds__(kScanBlock)
 scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ tile_off,
-                  int *__restrict__ out /* n + 1 */, const int *__restrict__ total) {
+                  int *__restrict__ out /* n + 1 */, const int *__restrict__ total,
+                  int *__restrict__ big /* voxels with more than kBigVoxel points */, int *__restrict__ nbig, int big_cap) {
   __shared__ int sh[kScanBlock];
   size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPer;
   int v[kScanPer]; int s = 0;
@@ -1786,8 +1794,26 @@ scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ 
     __syncthreads();
   }
   int run = tile_off[blockIdx.x] + sh[threadIdx.x] - s;
+  unsigned bigmask = 0;
 #pragma unroll
-  for (int k = 0; k < kScanPer; ++k) { if (base + k < n) out[base + k] = run; run += v[k]; }
+  for (int k = 0; k < kScanPer; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+    if (v[k] > kBigVoxel) bigmask |= 1u << k;
+  }
+  {                                              // list of the big voxels: one atomic per wave
+    const int mine = __builtin_popcount(bigmask), lane = threadIdx.x & 63;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    const int wave_total = __shfl(incl, 63);
+    int q0 = 0;
+    if (lane == 63 && wave_total > 0) q0 = atomicAdd(nbig, wave_total);
+    q0 = __shfl(q0, 63) + incl - mine;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k)
+      if ((bigmask >> k) & 1u) { if (q0 < big_cap) big[q0] = (int)(base + k); ++q0; }
+  }
   if (blockIdx.x == 0 && threadIdx.x < 4) out[n + threadIdx.x] = *total;   // out[n], + 3 readable copies
 }
 
@@ -1808,21 +1834,48 @@ map_scatter_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDi
 }
 
 // Restore input order inside every bucket (PCL accumulates a voxel's points in cloud order and
-// its float32 centroid sum depends on that order): one wave per voxel, rank by counting.
+// its float32 centroid sum depends on that order), rank by counting.  Voxels of up to kBigVoxel
+// points: eight lanes per voxel (one wave per voxel spent its time launching waves, 70 % of the
+// voxels being empty); the others, listed by scan_apply_kernel: one wave per voxel.
+constexpr int kOrderVoxPerBlock = 256 / 8 * 4;     // 32 lane groups, 4 voxels each
 __global__ void __launch_bounds__(256)
-map_order_kernel(const int *__restrict__ start, size_t ng, const int *__restrict__ perm,
-                 int *__restrict__ perm_sorted) {
-  size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (g >= ng) return;
-  const int lane = threadIdx.x & 63;
-  const int s0 = start[g], n = start[g + 1] - s0;
-  if (n <= 0) return;
-  if (n == 1) { if (lane == 0) perm_sorted[s0] = perm[s0]; return; }
-  for (int e = lane; e < n; e += 64) {
-    const int mine = perm[s0 + e];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) rank += (perm[s0 + j] < mine) ? 1 : 0;
-    perm_sorted[s0 + rank] = mine;
+map_order_small_kernel(const int *__restrict__ start, size_t ng, const int *__restrict__ perm,
+                       int *__restrict__ perm_sorted) {
+  const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  for (int r = 0; r < 4; ++r) {
+    const size_t g = (size_t)blockIdx.x * kOrderVoxPerBlock + (size_t)r * 32 + grp;
+    if (g >= ng) return;
+    const int s0 = start[g], n = start[g + 1] - s0;
+    if (n > kBigVoxel) continue;
+    for (int e = sub; e < n; e += 8) {
+      const int mine = perm[s0 + e];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (perm[s0 + j] < mine) ? 1 : 0;
+      perm_sorted[s0 + rank] = mine;
+    }
+  }
+}
+
+constexpr int kBigWavesPerBlock = 4, kBigBlocks = 1024, kBigStage = 512;   // LDS staging: point numbers per wave
+__global__ void __launch_bounds__(256)
+map_order_big_kernel(const int *__restrict__ start, const int *__restrict__ big, const int *__restrict__ nbig,
+                     int big_cap, const int *__restrict__ perm, int *__restrict__ perm_sorted) {
+  __shared__ int stage[kBigWavesPerBlock][kBigStage];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int count = min(*nbig, big_cap);
+  for (int q = blockIdx.x * kBigWavesPerBlock + wv; q < count; q += gridDim.x * kBigWavesPerBlock) {
+    const int g = big[q];
+    const int s0 = start[g], n = start[g + 1] - s0;
+    const bool staged = n <= kBigStage;
+    if (staged) for (int e = lane; e < n; e += 64) stage[wv][e] = perm[s0 + e];
+    __builtin_amdgcn_wave_barrier();            // one wave: its LDS writes are ordered before its later reads
+    for (int e = lane; e < n; e += 64) {
+      const int mine = staged ? stage[wv][e] : perm[s0 + e];
+      int rank = 0;
+      if (staged) { for (int j = 0; j < n; ++j) rank += (stage[wv][j] < mine) ? 1 : 0; }
+      else        { for (int j = 0; j < n; ++j) rank += (perm[s0 + j] < mine) ? 1 : 0; }
+      perm_sorted[s0 + rank] = mine;
+    }
   }
 }
 
@@ -1885,13 +1938,28 @@ __device__ int leaf_finalize(const LeafParams &L, int n, double sx, double sy, d
   return 1;
 }
 
-// One lane per voxel: sequential sums in cloud order (float32 centroid, fp64 mean / Sxx),
-// bucketed copy of the raw points, cell record.
+// Cell record of one voxel from its sums (shared by the two kernels below).
+__device__ __forceinline__ int write_voxel(const GridDims &G, const LeafParams &L, size_t g, int n, float fx, float fy,
+                                           double sx, double sy, double sxx, double sxy, double syy, double szz,
+                                           float2 *__restrict__ cent, double *__restrict__ rec, int *__restrict__ counters) {
+  if (n < L.min_pts) return 0;
+  const int ix = (int)(g % G.div_x), iy = (int)(g / G.div_x);
+  const size_t pg = (size_t)(iy + 2) * G.gw + (ix + 2);
+  double mean[2], icov[3];
+  const int ok = leaf_finalize(L, n, sx, sy, sxx, sxy, syy, szz, mean, icov);
+  cent[pg] = make_float2(fx / (float)n, fy / (float)n);
+  double *r = rec + pg * 8;
+  r[0] = mean[0]; r[1] = mean[1]; r[2] = icov[0]; r[3] = icov[1]; r[4] = icov[2];
+  return ok > 0 ? n : -n;
+}
+
+// One lane per voxel: sequential sums in cloud order (float32 centroid, fp64 mean / Sxx), bucketed
+// copy of the raw points, cell record.
 __global__ void __launch_bounds__(256)
 map_finalize_kernel(const float *__restrict__ xy, size_t stride, GridDims G, LeafParams L,
-                    const int *__restrict__ start, const int *__restrict__ perm_sorted,
-                    float2 *__restrict__ pts, float2 *__restrict__ cent, double *__restrict__ rec,
-                    int *__restrict__ npts_grid, int *__restrict__ counters /* n_cells, n_valid */) {
+                          const int *__restrict__ start, const int *__restrict__ perm_sorted,
+                          float2 *__restrict__ pts, float2 *__restrict__ cent, double *__restrict__ rec,
+                          int *__restrict__ npts_grid, int *__restrict__ counters /* n_cells, n_valid */) {
   const size_t ng = (size_t)G.div_x * G.div_y;
   size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   if (g >= ng) return;
@@ -1901,33 +1969,24 @@ map_finalize_kernel(const float *__restrict__ xy, size_t stride, GridDims G, Lea
     float fx = 0.f, fy = 0.f;
     double sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0, szz = 0;
     if (L.cov_init_identity) { sxx = 1.0; syy = 1.0; szz = 1.0; }
-    auto add = [&](int s, float2 p) {           // strictly in cloud order: these sums define the voxel
-      pts[s] = p;
-      fx += p.x; fy += p.y;
-      const double X = (double)p.x, Y = (double)p.y;
-      sx += X; sy += Y;
-      sxx += X * X; sxy += X * Y; syy += Y * Y;
-    };
-    int s = s0;
-    for (; s + 4 <= s1; s += 4) {               // four gathers in flight
-      const int i0 = perm_sorted[s], i1 = perm_sorted[s + 1], i2 = perm_sorted[s + 2], i3 = perm_sorted[s + 3];
-      const float2 p0 = load_pt(xy, stride, (size_t)i0), p1 = load_pt(xy, stride, (size_t)i1);
-      const float2 p2 = load_pt(xy, stride, (size_t)i2), p3 = load_pt(xy, stride, (size_t)i3);
-      add(s, p0); add(s + 1, p1); add(s + 2, p2); add(s + 3, p3);
+    for (int s = s0; s < s1; s += 8) {          // eight gathers in flight
+      int ib[8]; float2 pb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ib[u] = perm_sorted[min(s + u, s1 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pb[u] = load_pt(xy, stride, (size_t)ib[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (s + u >= s1) break;
+        const float2 p = pb[u];                 // strictly in cloud order: these sums define the voxel
+        pts[s + u] = p;
+        fx += p.x; fy += p.y;
+        const double X = (double)p.x, Y = (double)p.y;
+        sx += X; sy += Y;
+        sxx += X * X; sxy += X * Y; syy += Y * Y;
+      }
     }
-    for (; s < s1; ++s) add(s, load_pt(xy, stride, (size_t)perm_sorted[s]));
-    if (n >= L.min_pts) {
-      const int ix = (int)(g % G.div_x), iy = (int)(g / G.div_x);
-      const size_t pg = (size_t)(iy + 2) * G.gw + (ix + 2);
-      double mean[2], icov[3];
-      int ok = leaf_finalize(L, n, sx, sy, sxx, sxy, syy, szz, mean, icov);
-      cent[pg] = make_float2(fx / (float)n, fy / (float)n);
-      double *r = rec + pg * 8;
-      r[0] = mean[0]; r[1] = mean[1]; r[2] = icov[0]; r[3] = icov[1]; r[4] = icov[2];
-      flag = ok > 0 ? n : -n;
-      atomicAdd(&counters[0], 1);
-      if (ok > 0) atomicAdd(&counters[1], 1);
-    }
+    flag = write_voxel(G, L, g, n, fx, fy, sx, sy, sxx, sxy, syy, szz, cent, rec, counters);
   }
   npts_grid[g] = flag;
 }
@@ -1977,7 +2036,8 @@ struct ndt_map {
   int *perm = nullptr, *perm_sorted = nullptr; float2 *pts = nullptr;
   size_t perm_cap = 0, perm_sorted_cap = 0, pts_cap = 0;
   float2 *cent = nullptr; double *rec = nullptr; size_t cent_cap = 0, rec_cap = 0;
-  unsigned *bounds = nullptr; int *counters = nullptr; int *total = nullptr;
+  unsigned *bounds = nullptr; int *counters = nullptr; int *total = nullptr;   // counters: n_cells, n_valid, n_big
+  int *big = nullptr; size_t big_cap = 0;
   void *d_xy_stage = nullptr; size_t d_xy_cap = 0;
 };
 
@@ -2161,7 +2221,7 @@ int ndt_map_destroy(ndt_map *m) {
   if (!m) return NDT_E_ARG;
   hipError_t e = hipSetDevice(m->ctx->device);
   e = hipStreamSynchronize(m->ctx->stream);
-  void *bufs[] = {m->count, m->start, m->fill, m->tile, m->npts_grid, m->perm, m->perm_sorted, m->pts,
+  void *bufs[] = {m->big, m->count, m->start, m->fill, m->tile, m->npts_grid, m->perm, m->perm_sorted, m->pts,
                   m->cent, m->rec, m->bounds, m->counters, m->total, m->d_xy_stage};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
@@ -2183,7 +2243,7 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
     if (!m) return NDT_E_NOMEM;
     m->ctx = ctx;
     HIP_TRY(ctx, hipMalloc(&m->bounds, 4 * sizeof(unsigned)));
-    HIP_TRY(ctx, hipMalloc(&m->counters, 2 * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc(&m->counters, 4 * sizeof(int)));
     HIP_TRY(ctx, hipMalloc(&m->total, sizeof(int)));
     *pmap = m;
   }
@@ -2221,13 +2281,14 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
     if ((rc = ensure_t(ctx, &m->tile, &m->tile_cap, ntiles_ + 1))) return rc;
     if ((rc = ensure_t(ctx, &m->perm, &m->perm_cap, n))) return rc;
     if ((rc = ensure_t(ctx, &m->perm_sorted, &m->perm_sorted_cap, n))) return rc;
+    if ((rc = ensure_t(ctx, &m->big, &m->big_cap, n / kBigVoxel + 1))) return rc;   // voxels with > kBigVoxel points
     if ((rc = ensure_t(ctx, &m->pts, &m->pts_cap, n))) return rc;
     if ((rc = ensure_t(ctx, &m->cent, &m->cent_cap, npad))) return rc;
     if ((rc = ensure_t(ctx, &m->rec, &m->rec_cap, npad * 8))) return rc;
   }
   HIP_TRY(ctx, hipMemsetAsync(m->count, 0, (ng + 1) * sizeof(int), st));
   HIP_TRY(ctx, hipMemsetAsync(m->fill, 0, (ng + 1) * sizeof(int), st));
-  HIP_TRY(ctx, hipMemsetAsync(m->counters, 0, 2 * sizeof(int), st));
+  HIP_TRY(ctx, hipMemsetAsync(m->counters, 0, 4 * sizeof(int), st));
   HIP_TRY(ctx, hipMemsetAsync(m->rec, 0, npad * 8 * sizeof(double), st));
   fill_f2_kernel<<<grid_for(npad, 256), 256, 0, st>>>(m->cent, npad, INFINITY);
 
@@ -2238,17 +2299,19 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
   scan_tile_offsets_kernel<<<1, 1024, 0, st>>>(m->tile, ntiles, m->total);
   HIP_TRY(ctx, hipMemsetAsync(m->start, 0, 4 * sizeof(int), st));
   int *const start = m->start + 4;
-  scan_apply_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, start, m->total);
+  const int big_cap = (int)(n / kBigVoxel + 1);
+  scan_apply_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, start, m->total, m->big, m->counters + 2, big_cap);
   map_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, start, m->fill, m->perm);
-  map_order_kernel<<<(unsigned)((ng + 3) / 4), 256, 0, st>>>(start, ng, m->perm, m->perm_sorted);
+  map_order_small_kernel<<<(unsigned)((ng + kOrderVoxPerBlock - 1) / kOrderVoxPerBlock), 256, 0, st>>>(start, ng, m->perm, m->perm_sorted);
+  map_order_big_kernel<<<kBigBlocks, 256, 0, st>>>(start, m->big, m->counters + 2, big_cap, m->perm, m->perm_sorted);
 
   // 4. per-voxel statistics -> centroid grid + cell records + bucketed raw points
   LeafParams L;
   L.min_pts = prm->min_pts; L.cov_unbiased = prm->cov_unbiased; L.cov_init_identity = prm->cov_init_identity;
   L.eig_mult = prm->eig_mult;
   map_finalize_kernel<<<(unsigned)((ng + 255) / 256), 256, 0, st>>>(xy, stride, G, L, start, m->perm_sorted,
-                                                                    m->pts, m->cent, m->rec, m->npts_grid,
-                                                                    m->counters);
+                                                                          m->pts, m->cent, m->rec, m->npts_grid,
+                                                                          m->counters);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
 
@@ -2287,11 +2350,14 @@ int ndt_map_info_get(const ndt_map *cm, ndt_map_info *out) {
   if (!cm || !out) return NDT_E_ARG;
   ndt_map *m = const_cast<ndt_map *>(cm);
   if (!m->info_valid) {
-    int c[2];
+    // per-voxel flags: 0 not in the search set, n accepted, -n rejected covariance
+    std::vector<int> flags(m->ng);
     HIP_TRY(m->ctx, hipSetDevice(m->ctx->device));
-    HIP_TRY(m->ctx, hipMemcpyAsync(c, m->counters, sizeof(c), hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_TRY(m->ctx, hipMemcpyAsync(flags.data(), m->npts_grid, m->ng * sizeof(int), hipMemcpyDeviceToHost, m->ctx->stream));
     HIP_TRY(m->ctx, hipStreamSynchronize(m->ctx->stream));
-    m->info.n_cells = c[0]; m->info.n_valid = c[1];
+    int cells = 0, valid = 0;
+    for (int f : flags) { cells += f != 0; valid += f > 0; }
+    m->info.n_cells = cells; m->info.n_valid = valid;
     m->info_valid = true;
   }
   *out = m->info;
