@@ -265,10 +265,6 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
   const unsigned short *srow = W.slot + (cly - 1) * R.rw + (clx - 1);
   unsigned mask = 0;
   float lowx = INFINITY;                       // -inf <=> one of the nine voxels is occupied but not resident
-#ifdef NDT_EXP_NO_PROBES
-  if (xt == 12345.678f) A.e += (double)srow[0];  // experiment: no LDS probes at all
-  return;
-#endif
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -277,9 +273,6 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
       lowx = fminf(lowx, cc.x);
       mask |= in_radius<INCL>(M.r2, xt, yt, cc) << (r * 3 + q);
     }
-#ifdef NDT_EXP_NO_CELLS
-  mask = 0;                                     // experiment: probes only
-#endif
   if (inwin & (lowx != -INFINITY)) {
     if (!mask) return;
     A.pairs += __builtin_popcount(mask);
@@ -2006,7 +1999,10 @@ struct ndt_ctx {
   int device = 0;
   hipStream_t stream = nullptr;       // the stream all work is ordered on
   hipStream_t own_stream = nullptr;   // created by ndt_ctx_create
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the last match launch
+  hipEvent_t evm0 = nullptr, evm1 = nullptr; // around the last map build
+  bool map_ms_pending = false;
+  unsigned *h_bounds = nullptr;              // pinned: bounding box read-back of the map build
   std::string err;
   float map_ms = 0.f, align_ms = 0.f;
   // grow-only staging for the host-pointer entry points
@@ -2170,6 +2166,9 @@ int ndt_ctx_create(int device, ndt_ctx **out) {
   c->stream = c->own_stream;
   HIP_TRY(c, hipEventCreate(&c->ev0));
   HIP_TRY(c, hipEventCreate(&c->ev1));
+  HIP_TRY(c, hipEventCreate(&c->evm0));
+  HIP_TRY(c, hipEventCreate(&c->evm1));
+  HIP_TRY(c, hipHostMalloc((void **)&c->h_bounds, 64, hipHostMallocDefault));
   { int rc = upload_exp_table(c); if (rc) return rc; }
   {
     hipDeviceProp_t prop;
@@ -2193,6 +2192,9 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->own_stream) e = hipStreamDestroy(c->own_stream);
   if (c->ev0) e = hipEventDestroy(c->ev0);
   if (c->ev1) e = hipEventDestroy(c->ev1);
+  if (c->evm0) e = hipEventDestroy(c->evm0);
+  if (c->evm1) e = hipEventDestroy(c->evm1);
+  if (c->h_bounds) e = hipHostFree(c->h_bounds);
   void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_ws};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
@@ -2210,8 +2212,14 @@ int ndt_ctx_set_stream(ndt_ctx *c, void *stream) {
   return NDT_OK;
 }
 
-int ndt_last_timing(const ndt_ctx *c, float *map_ms, float *align_ms) {
-  if (!c) return NDT_E_ARG;
+int ndt_last_timing(const ndt_ctx *cc, float *map_ms, float *align_ms) {
+  if (!cc) return NDT_E_ARG;
+  ndt_ctx *c = const_cast<ndt_ctx *>(cc);
+  if (c->map_ms_pending) {                     // the device-pointer build returns before its last kernels end
+    HIP_TRY(c, hipEventSynchronize(c->evm1));
+    HIP_TRY(c, hipEventElapsedTime(&c->map_ms, c->evm0, c->evm1));
+    c->map_ms_pending = false;
+  }
   if (map_ms) *map_ms = c->map_ms;
   if (align_ms) *align_ms = c->align_ms;
   return NDT_OK;
@@ -2248,14 +2256,14 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
     *pmap = m;
   }
   m->prm = *prm; m->n = n; m->info_valid = false;
-  HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
+  HIP_TRY(ctx, hipEventRecord(ctx->evm0, st));
 
   // 1. bounding box (getMinMax3D)
   unsigned init_b[4] = {0xffffffffu, 0xffffffffu, 0u, 0u};
   HIP_TRY(ctx, hipMemcpyAsync(m->bounds, init_b, sizeof(init_b), hipMemcpyHostToDevice, st));
   map_minmax_kernel<<<grid_for(n, 256 * 16, 512), 256, 0, st>>>(xy, stride, n, m->bounds);
-  unsigned hb[4];
-  HIP_TRY(ctx, hipMemcpyAsync(hb, m->bounds, sizeof(hb), hipMemcpyDeviceToHost, st));
+  unsigned *hb = ctx->h_bounds;                // pinned
+  HIP_TRY(ctx, hipMemcpyAsync(hb, m->bounds, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   if (hb[0] == 0xffffffffu) return fail(ctx, NDT_E_ARG, "ndt_map_build: no finite points");
   const float inv_leaf = 1.0f / prm->resolution;
@@ -2289,7 +2297,7 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
   HIP_TRY(ctx, hipMemsetAsync(m->count, 0, (ng + 1) * sizeof(int), st));
   HIP_TRY(ctx, hipMemsetAsync(m->fill, 0, (ng + 1) * sizeof(int), st));
   HIP_TRY(ctx, hipMemsetAsync(m->counters, 0, 4 * sizeof(int), st));
-  HIP_TRY(ctx, hipMemsetAsync(m->rec, 0, npad * 8 * sizeof(double), st));
+  // (records of voxels outside the search set are never read: no clearing of m->rec)
   fill_f2_kernel<<<grid_for(npad, 256), 256, 0, st>>>(m->cent, npad, INFINITY);
 
   // 3. bucket the points by voxel, cloud order kept inside a bucket
@@ -2313,7 +2321,8 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
                                                                           m->pts, m->cent, m->rec, m->npts_grid,
                                                                           m->counters);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+  HIP_TRY(ctx, hipEventRecord(ctx->evm1, st));
+  ctx->map_ms_pending = true;
 
   MapView &V = m->view;
   V.inv_leaf = inv_leaf; V.leaf = prm->resolution;
@@ -2324,9 +2333,7 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
   gauss_constants(*prm, &V.d1, &V.d2);
   m->info.min_bx = G.min_bx; m->info.min_by = G.min_by; m->info.div_x = G.div_x; m->info.div_y = G.div_y;
   m->info.n_points = n;
-  HIP_TRY(ctx, hipEventSynchronize(ctx->ev1));
-  HIP_TRY(ctx, hipEventElapsedTime(&ctx->map_ms, ctx->ev0, ctx->ev1));
-  return NDT_OK;
+  return NDT_OK;                               // asynchronous from here on (stream order)
 }
 
 int ndt_map_build(ndt_ctx *ctx, const float *xy_host, size_t n, size_t stride, const ndt_params *prm,
@@ -2341,6 +2348,7 @@ int ndt_map_build(ndt_ctx *ctx, const float *xy_host, size_t n, size_t stride, c
   if (rc) return rc;
   HIP_TRY(ctx, hipMemcpyAsync(stage, xy_host, n * stride, hipMemcpyHostToDevice, ctx->stream));
   rc = ndt_map_build_dev(ctx, (const float *)stage, n, stride, prm, pmap);
+  if (rc == NDT_OK) { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) rc = fail(ctx, NDT_E_HIP, hipGetErrorString(e)); }   // host-pointer form: synchronous
   if (*pmap) { (*pmap)->d_xy_stage = stage; (*pmap)->d_xy_cap = cap; }
   else { hipError_t e = hipFree(stage); (void)e; }
   return rc;
@@ -2405,6 +2413,7 @@ int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, co
   if (!map || !scans || !offsets || !inits || !out || B <= 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: bad arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  if (st != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->evm1, 0));   // the map build may still be running on the context's stream
   float2 *sorted = nullptr;
   if (!shared_scan && total_points > 0) {
     int rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, total_points * 8);
