@@ -738,7 +738,8 @@ constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / 64;
 constexpr int kSub = 4;                      // a lane's points are cut into kSub runs -> kSub units per wave
 constexpr int kUnits = kWaves * kSub;        // units per pass
-constexpr int kMaxHelpers = 7;               // helper workgroups per scan (16 units: 2 each)
+constexpr int kMaxHelpers = 15;              // helper workgroups per scan, hard limit (64 units: 4 each)
+constexpr int kBaseHelpers = 7;              // ... while more scans are unfinished than workgroups / 8
 constexpr unsigned kEpochDone = 0xFFFFFFFFu;
 constexpr unsigned long long kWatchTicks = 400000000ull;   // ~4 s of the 100 MHz wall clock
 
@@ -1464,12 +1465,16 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     if (threadIdx.x == 0) { L.sflag[0] = INT_MAX; L.sflag[3] = 0; }
     __syncthreads();
     const int start = (int)((blockIdx.x * 97u) % (unsigned)B);
+    // helpers per scan: as many as the unfinished scans leave workgroups for (the last stragglers get
+    // up to kMaxHelpers, a unit each per wave)
+    const int unfinished = max(1, B - (int)ld32(&hdr->done));
+    const int room = min(allow_helpers, max(min(allow_helpers, kBaseHelpers), (int)gridDim.x / unfinished - 1));
     for (int k = threadIdx.x; k < B; k += kBlock) {
       int b = start + k; if (b >= B) b -= B;
       const u32 ep = (u32)(rd64_fresh(&ctl[b].ticket) >> 32);
       if (ep == 0u || ep == kEpochDone) continue;
       const u32 h = rd32_fresh(&ctl[b].helpers);
-      if (h >= (u32)allow_helpers) continue;
+      if (h >= (u32)room) continue;
       // a scan that already needed many passes will likely need many more: most passes first,
       // each attached helper counting like 4 passes fewer; then nearest
       const int score = (int)min(ld32(&ctl[b].passes), 200u) - 4 * (int)h;       // -28 .. 200
@@ -1483,7 +1488,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       else if (L.sflag[0] != INT_MAX) {
         int b = start + (L.sflag[0] & 0xFFFFF); if (b >= B) b -= B;
         const u32 h = __hip_atomic_fetch_add(&ctl[b].helpers, 1u, NDT_RLX, NDT_AGENT);
-        if (h >= (u32)allow_helpers) {
+        if (h >= (u32)room) {
           __hip_atomic_fetch_sub(&ctl[b].helpers, 1u, NDT_RLX, NDT_AGENT);   // lost the race: look again
         } else {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // geometry + ordered copy of the owner

@@ -212,6 +212,60 @@ def test_full_size_batch_properties(gpu, oracle):
         assert_result_parity(r1[b], ref)
 
 
+def test_results_do_not_depend_on_work_sharing(gpu):
+    """A batch smaller than the chip (idle workgroups help from the start) gives byte-identical
+    records with work sharing switched off: unit totals are summed in unit order whoever computed them."""
+    import os
+    capi, ctx = gpu
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C3"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    scans, off, truths, inits = sf.batch(40, 48)
+    prm = capi.default_params(resolution=cfg["resolution"])
+    shared = capi.Map(ctx, m, prm).align_batch(scans, off, inits)
+    os.environ["NDT_NO_HELPERS"] = "1"
+    try:
+        solo_ctx = capi.Context(0)
+    finally:
+        del os.environ["NDT_NO_HELPERS"]
+    solo = capi.Map(solo_ctx, m, prm).align_batch(scans, off, inits)
+    assert np.all(shared["status"] == 0) and shared.tobytes() == solo.tobytes()
+
+
+def test_ragged_batch_with_more_scans_than_workgroups(gpu, oracle, c1_world):
+    """More scans than CUs (owners take several scans each), lengths from 1 point to the full scan."""
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    B = 300
+    parts, inits, lens = [], [], []
+    for b in range(B):
+        scan, truth, init = sf.make(b % 16)
+        n = 1 + (b * 37) % len(scan) if b % 5 else len(scan)
+        parts.append(scan[:n]); inits.append(init); lens.append(n)
+    scans = np.concatenate(parts); off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    res = gm.align_batch(scans, off, np.array(inits))
+    assert np.all(res["status"] == 0)
+    for b in list(range(0, B, 23)) + [B - 1]:
+        assert_result_parity(res[b], om.align(parts[b], inits[b]))
+
+
+def test_scan_larger_than_the_sort_capacity(gpu, oracle):
+    """A 25k-point scan: above the LDS room of the spatial sort, the passes read it in input order."""
+    capi, ctx = gpu
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C2"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], 25000)
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    scan, truth, init = sf.make(3)
+    assert len(scan) == 25000
+    assert_result_parity(gm.align(scan, init), om.align(scan, init))
+
+
 def test_multi_hypothesis_shared_scan(gpu, oracle, c1_world):
     """configs[4] shape at small size: many seed poses x one scan."""
     capi, ctx = gpu
