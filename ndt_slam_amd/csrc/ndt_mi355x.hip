@@ -48,6 +48,7 @@ struct MapView {
                                      // the centroid search set (fewer than min_pts points)
   const double *rec;                 // gw*gh records of 8 doubles (64 B):
                                      // mean_x, mean_y, icov_xx, icov_xy, icov_yy, 3 pad
+  const unsigned *occ;               // one bit per voxel of the unpadded grid: in the centroid search set
   const int *pt_start;               // div_x*div_y + 1 bucket offsets of the raw points
   const float2 *pts;                 // raw points bucketed by voxel, input order kept (a7)
   double d1, d2;                     // Gaussian constants (a3)
@@ -739,6 +740,9 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kSub = 4;                      // a lane's points are cut into kSub runs -> kSub units per wave
 constexpr int kUnits = kWaves * kSub;        // units per pass
 constexpr int kMaxHelpers = 15;              // helper workgroups per scan, hard limit (64 units: 4 each)
+#ifndef NDT_HELPER_PENALTY
+#define NDT_HELPER_PENALTY 12    // passes a scan must be ahead by before it gets one more helper than another
+#endif
 constexpr int kBaseHelpers = 7;              // ... while more scans are unfinished than workgroups / 8
 constexpr unsigned kEpochDone = 0xFFFFFFFFu;
 constexpr unsigned long long kWatchTicks = 400000000ull;   // ~4 s of the 100 MHz wall clock
@@ -814,6 +818,7 @@ struct Lds {
   unsigned long long hword;        // helper: epoch word seen by wave 0
   int hrank;                       // helper: order of registration on its scan
   int jnext, stop;                 // units of the open segment handed out so far; close the segment
+  unsigned diag[2];                // diagnostic: ticks of fill_window's first two phases
   double etab[64];
 };
 
@@ -888,46 +893,67 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
   const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
   unsigned short *slot = reinterpret_cast<unsigned short *>(pool);
   CellEntry *ent = reinterpret_cast<CellEntry *>(reinterpret_cast<char *>(pool) + ((r.rw * r.rh * 2 + 15) / 16) * 16);
+  const u64 t_fill0 = wall_clock64();
   const int ncell = r.rw * r.rh;
   const int rounds = (ncell + kBlock - 1) / kBlock;          // <= kRegionCells / kBlock = 16
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u64 *keepw = reinterpret_cast<u64 *>(L.wpart) + 256;        // [rounds][kWaves] ballots (wmap uses the first 2 KiB)
   u64 *occw = keepw + 256;
   int *base = reinterpret_cast<int *>(L.wtmp);                // [256] exclusive prefix of the kept counts
-  // any marked cell in columns [lx-2, lx+2] of row yy
-  auto row_marked = [&](int yy, int lx) {
-    const int xa = max(lx - 2, 0), xb = min(lx + 2, r.rw - 1);
-    const int b0 = yy * r.rw + xa, len = xb - xa + 1;
-    const unsigned lo = wmap[b0 >> 5], hi = wmap[min((b0 >> 5) + 1, kRegionCells / 32 - 1)];
-    const u64 both = ((u64)hi << 32) | lo;
-    return ((both >> (b0 & 31)) & ((1ull << len) - 1ull)) != 0ull;
-  };
-  for (int j0 = 0; j0 < rounds; j0 += 4) {                   // four rounds' centroid loads in flight together
-    float cx[4];
+  // which window cells are in the map's search set: one bit each from the map's occupancy words,
+  // all rounds' loads in flight together, then one ballot per round
+  unsigned ow[kRegionCells / kBlock];
+  const int rw1 = max(r.rw, 1), step_y = kBlock / rw1, step_x = kBlock - step_y * rw1;   // one round further on
+  int ly = (int)threadIdx.x / rw1, lx = (int)threadIdx.x - ly * rw1;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int c = (j0 + u) * kBlock + threadIdx.x;
-      cx[u] = INFINITY;
-      if (c < ncell) { const int ly = c / r.rw, lx = c - ly * r.rw; cx[u] = M.cent[(size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2)].x; }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = j0 + u, c = j * kBlock + threadIdx.x;
-      if (j >= rounds) break;
-      const bool occ = cx[u] < INFINITY;        // +inf marks voxels outside the search set
-      bool keep = false;
-      if (occ) {
-        const int ly = c / r.rw, lx = c - ly * r.rw;
-        for (int dy = -2; dy <= 2 && !keep; ++dy) {
-          const int yy = ly + dy;
-          if (yy >= 0 && yy < r.rh) keep = row_marked(yy, lx);
-        }
+  for (int j = 0; j < kRegionCells / kBlock; ++j) {
+    const int c = j * kBlock + threadIdx.x;
+    ow[j] = 0u;
+    if (j < rounds && c < ncell) {
+      const int mx = r.x0 + lx, my = r.y0 + ly;
+      if (mx >= 0 && mx < M.div_x && my >= 0 && my < M.div_y) {
+        const size_t g = (size_t)my * M.div_x + mx;
+        ow[j] = (M.occ[g >> 5] >> (g & 31)) & 1u;
       }
-      const u64 kb = __ballot(keep), ob = __ballot(occ);
-      if (lane == 0) { keepw[j * kWaves + wave] = kb; occw[j * kWaves + wave] = ob; }
     }
+    lx += step_x; ly += step_y;
+    if (lx >= rw1) { lx -= rw1; ++ly; }
+  }
+#pragma unroll
+  for (int j = 0; j < kRegionCells / kBlock; ++j) {
+    const u64 ob = __ballot(ow[j] != 0u);
+    if (lane == 0) occw[j * kWaves + wave] = ob;           // rounds past the window: zero
+  }
+  // marked cells dilated by two cells in x and y, on whole words: a voxel gets an LDS record when it
+  // is in the search set and within two cells of a cell a scan point fell in.  (Rows are not word
+  // aligned, so a mark in the first or last two columns of the window also reaches the end of the
+  // neighbouring row: a few more records, nothing else.)
+  unsigned *dx = reinterpret_cast<unsigned *>(keepw);       // 512 words, reused for the result
+  constexpr int kWords = kRegionCells / 32;
+  auto word_at = [&](const unsigned *a, int i) { return (i >= 0 && i < kWords) ? a[i] : 0u; };
+  if (threadIdx.x < kWords) {
+    const int i = threadIdx.x;
+    const unsigned w = wmap[i], pv = word_at(wmap, i - 1), nx = word_at(wmap, i + 1);
+    dx[i] = w | (w << 1) | (w << 2) | (w >> 1) | (w >> 2) | (pv >> 31) | (pv >> 30) | (nx << 31) | (nx << 30);
   }
   __syncthreads();
+  unsigned kword = 0;
+  if (threadIdx.x < kWords) {
+    const int i = threadIdx.x;
+    kword = dx[i];
+#pragma unroll
+    for (int m = 1; m <= 2; ++m) {
+      const int sft = m * r.rw, q = sft >> 5, b = sft & 31;
+      // bits moved towards higher cell numbers (from the row(s) above) and towards lower ones (below)
+      kword |= (word_at(dx, i - q) << b) | (b ? (word_at(dx, i - q - 1) >> (32 - b)) : 0u);
+      kword |= (word_at(dx, i + q) >> b) | (b ? (word_at(dx, i + q + 1) << (32 - b)) : 0u);
+    }
+    kword &= reinterpret_cast<const unsigned *>(occw)[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < kWords) dx[threadIdx.x] = kword;        // = keepw, two words per ballot word
+  __syncthreads();
+  if (threadIdx.x == 0) L.diag[0] = (unsigned)(wall_clock64() - t_fill0);
   // exclusive prefix of the kept counts over the rounds * kWaves ballot words (cell order)
   const int nword = rounds * kWaves;                           // <= 256
   if (threadIdx.x < 256) {
@@ -956,6 +982,7 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
     z.cent = make_float2(-INFINITY, -INFINITY);
     ent[r.cap + 1] = z;                         // occupied voxels without an LDS record
     L.RG.nspill = skipped + (kept > r.cap ? kept - r.cap : 0);
+    L.diag[1] = (unsigned)(wall_clock64() - t_fill0);
   }
   __syncthreads();
   for (int j0 = 0; j0 < rounds; j0 += 4) {                   // four rounds' record loads in flight together
@@ -1268,7 +1295,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       if (prof && threadIdx.x == 0) {
         const u64 q4 = wall_clock64();
         prof[8 * (size_t)B + 8 * (size_t)b + 6] = ((q1 - q0) << 32) | ((q2 - q1) & 0xFFFFFFFFull);
-        prof[8 * (size_t)B + 8 * (size_t)b + 7] = ((q3 - q2) << 32) | ((q4 - q3) & 0xFFFFFFFFull);
+        prof[8 * (size_t)B + 8 * (size_t)b + 7] = ((q3 - q2) << 32) | ((u64)(L.diag[0] & 0xFFFFu) << 16) | (u64)(L.diag[1] & 0xFFFFu);
       }
       if (allow_helpers) {
         // publish geometry + ordered copy: plain stores, drained by every wave, then one agent release
@@ -1477,8 +1504,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       if (h >= (u32)room) continue;
       // a scan that already needed many passes will likely need many more: most passes first,
       // each attached helper counting like 4 passes fewer; then nearest
-      const int score = (int)min(ld32(&ctl[b].passes), 200u) - 4 * (int)h;       // -28 .. 200
-      atomicMin(&L.sflag[0], (int)(((u32)(256 - score) << 20) | (u32)k));
+      const int score = (int)min(ld32(&ctl[b].passes), 200u) - NDT_HELPER_PENALTY * (int)h;
+      atomicMin(&L.sflag[0], (int)(((u32)(512 - score) << 20) | (u32)k));
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1957,11 +1984,14 @@ __global__ void __launch_bounds__(256)
 map_finalize_kernel(const float *__restrict__ xy, size_t stride, GridDims G, LeafParams L,
                           const int *__restrict__ start, const int *__restrict__ perm_sorted,
                           float2 *__restrict__ pts, float2 *__restrict__ cent, double *__restrict__ rec,
-                          int *__restrict__ npts_grid, int *__restrict__ counters /* n_cells, n_valid */) {
+                          int *__restrict__ npts_grid, int *__restrict__ counters /* unused */,
+                          unsigned *__restrict__ occ /* (ng + 31) / 32 words: voxel in the search set */) {
   const size_t ng = (size_t)G.div_x * G.div_y;
   size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (g >= ng) return;
-  const int s0 = start[g], s1 = start[g + 1], n = s1 - s0;
+  const bool live = g < ng;
+  int s0 = 0, s1 = 0;
+  if (live) { s0 = start[g]; s1 = start[g + 1]; }
+  const int n = s1 - s0;
   int flag = 0;
   if (n > 0) {
     float fx = 0.f, fy = 0.f;
@@ -1986,7 +2016,12 @@ map_finalize_kernel(const float *__restrict__ xy, size_t stride, GridDims G, Lea
     }
     flag = write_voxel(G, L, g, n, fx, fy, sx, sy, sxx, sxy, syy, szz, cent, rec, counters);
   }
-  npts_grid[g] = flag;
+  if (live) npts_grid[g] = flag;
+  const u64 in_set = __ballot(flag != 0);       // the wave's 64 consecutive voxels (blockDim is a multiple of 64)
+  if ((threadIdx.x & 63) == 0 && live) {
+    occ[g >> 5] = (unsigned)in_set;
+    if ((g >> 5) + 1 < (ng + 31) / 32) occ[(g >> 5) + 1] = (unsigned)(in_set >> 32);
+  }
 }
 
 __global__ void fill_f2_kernel(float2 *p, size_t n, float v) {
@@ -2039,6 +2074,7 @@ struct ndt_map {
   float2 *cent = nullptr; double *rec = nullptr; size_t cent_cap = 0, rec_cap = 0;
   unsigned *bounds = nullptr; int *counters = nullptr; int *total = nullptr;   // counters: n_cells, n_valid, n_big
   int *big = nullptr; size_t big_cap = 0;
+  unsigned *occ = nullptr; size_t occ_cap = 0;
   void *d_xy_stage = nullptr; size_t d_xy_cap = 0;
 };
 
@@ -2234,7 +2270,7 @@ int ndt_map_destroy(ndt_map *m) {
   if (!m) return NDT_E_ARG;
   hipError_t e = hipSetDevice(m->ctx->device);
   e = hipStreamSynchronize(m->ctx->stream);
-  void *bufs[] = {m->big, m->count, m->start, m->fill, m->tile, m->npts_grid, m->perm, m->perm_sorted, m->pts,
+  void *bufs[] = {m->occ, m->big, m->count, m->start, m->fill, m->tile, m->npts_grid, m->perm, m->perm_sorted, m->pts,
                   m->cent, m->rec, m->bounds, m->counters, m->total, m->d_xy_stage};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
@@ -2295,6 +2331,7 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
     if ((rc = ensure_t(ctx, &m->perm, &m->perm_cap, n))) return rc;
     if ((rc = ensure_t(ctx, &m->perm_sorted, &m->perm_sorted_cap, n))) return rc;
     if ((rc = ensure_t(ctx, &m->big, &m->big_cap, n / kBigVoxel + 1))) return rc;   // voxels with > kBigVoxel points
+    if ((rc = ensure_t(ctx, &m->occ, &m->occ_cap, (ng + 31) / 32 + 2))) return rc;
     if ((rc = ensure_t(ctx, &m->pts, &m->pts_cap, n))) return rc;
     if ((rc = ensure_t(ctx, &m->cent, &m->cent_cap, npad))) return rc;
     if ((rc = ensure_t(ctx, &m->rec, &m->rec_cap, npad * 8))) return rc;
@@ -2324,7 +2361,7 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
   L.eig_mult = prm->eig_mult;
   map_finalize_kernel<<<(unsigned)((ng + 255) / 256), 256, 0, st>>>(xy, stride, G, L, start, m->perm_sorted,
                                                                           m->pts, m->cent, m->rec, m->npts_grid,
-                                                                          m->counters);
+                                                                          m->counters, m->occ);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipEventRecord(ctx->evm1, st));
   ctx->map_ms_pending = true;
@@ -2334,7 +2371,7 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
   V.r2 = (float)((double)prm->resolution * (double)prm->resolution);
   V.radius_inclusive = prm->radius_inclusive; V.transform_sse = prm->transform_sse;
   V.min_bx = G.min_bx; V.min_by = G.min_by; V.div_x = G.div_x; V.div_y = G.div_y; V.gw = G.gw; V.gh = G.gh;
-  V.cent = m->cent; V.rec = m->rec; V.pt_start = start; V.pts = m->pts;
+  V.cent = m->cent; V.rec = m->rec; V.occ = m->occ; V.pt_start = start; V.pts = m->pts;
   gauss_constants(*prm, &V.d1, &V.d2);
   m->info.min_bx = G.min_bx; m->info.min_by = G.min_by; m->info.div_x = G.div_x; m->info.div_y = G.div_y;
   m->info.n_points = n;

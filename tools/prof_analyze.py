@@ -25,6 +25,6 @@ if n > 0:
     print("shared derivative passes %d: prologue %.2f own units %.2f wait %.2f combine %.2f advance %.2f us (means)" %
           (n, p2[:, 1].sum() / n * 0.01, p2[:, 2].sum() / n * 0.01, p2[:, 3].sum() / n * 0.01, p2[:, 4].sum() / n * 0.01, p2[:, 5].sum() / n * 0.01))
 raw2 = raw[8 * B:].reshape(B, 8)
-print("setup phases us (means): region %.1f sort %.1f fill %.1f partition %.1f" % (
+print("setup phases us (means): region %.1f sort %.1f fill %.1f (marking %.1f, numbering done at %.1f)" % (
     (raw2[:, 6] >> 32).mean() * 0.01, (raw2[:, 6] & 0xFFFFFFFF).mean() * 0.01,
-    (raw2[:, 7] >> 32).mean() * 0.01, (raw2[:, 7] & 0xFFFFFFFF).mean() * 0.01))
+    (raw2[:, 7] >> 32).mean() * 0.01, ((raw2[:, 7] >> 16) & 0xFFFF).mean() * 0.01, (raw2[:, 7] & 0xFFFF).mean() * 0.01))
