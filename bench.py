@@ -36,6 +36,19 @@ def algorithmic_bytes(res, n_pts):
     return float(np.sum(ev * n_pts * (8.0 + 20.0 * kb) + n_pts * 16.0))
 
 
+def measured_traffic():
+    """HBM bytes per launch of the match kernel from the PMC passes committed under profiles/
+    (FETCH_SIZE + WRITE_SIZE, collected separately with rocprofv3 -- they cannot be read live here);
+    None when no summary is present."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    return float(t["bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +141,7 @@ def main():
     out = None
     if rank == 0:
         avg_kern_ms = float(np.mean(kern_ms))
+        traffic, traffic_src = measured_traffic()
         alg_bytes = algorithmic_bytes(res, n_scan)
         achieved = alg_bytes / (avg_kern_ms * 1e-3) / 1e9
         err = res["pose"] - truths
@@ -146,7 +160,7 @@ def main():
                        "scans_per_gpu": B, "scan_points": n_scan, "map_points": cfg["n_map"],
                        "resolution": cfg["resolution"], "parallelism": "scan-shards x%d, gather of results" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "ndt_align_kernel", "kernel_ms": avg_kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "mean_evals": float(res["evals"].mean()), "max_evals": int(res["evals"].max()),
