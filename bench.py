@@ -95,7 +95,12 @@ def main():
     d_scans = torch.from_numpy(scans).to(dev)
     d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
     d_init = torch.from_numpy(inits).to(dev)
-    d_res = torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+    d_res2 = [torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev) for _ in range(2)]
+    d_res = d_res2[0]
+    # the gather of step i runs on a side stream while step i + 1 is already computing
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    ev_done = [torch.cuda.Event() for _ in range(2)]
+    gathered = [None, None]
     torch.cuda.synchronize()
     gmap = capi.Map(ctx, params=prm, dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
 
@@ -108,11 +113,17 @@ def main():
         gmap.rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
         # a3-a9 for the whole batch: one launch on torch's current stream
         ev_a[2 * i].record(stream)
+        out = d_res2[i & 1]
+        if world > 1:
+            stream.wait_event(ev_done[i & 1])          # its previous gather has finished
         gmap.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, len(scans), d_init.data_ptr(),
-                             d_res.data_ptr(), stream=stream.cuda_stream)
+                             out.data_ptr(), stream=stream.cuda_stream)
         ev_a[2 * i + 1].record(stream)
         if world > 1:    # gather of poses (the only collective on this path)
-            shard.gather_results(d_res, dst=0)
+            side.wait_stream(stream)
+            with torch.cuda.stream(side):
+                gathered[i & 1] = shard.gather_results(out, dst=0)
+                ev_done[i & 1].record(side)
 
     def fence():
         torch.cuda.synchronize()
@@ -135,7 +146,8 @@ def main():
 
     kern_ms = [ev_a[2 * i].elapsed_time(ev_a[2 * i + 1]) for i in range(args.warmup, args.warmup + args.steps)]
     map_ms = [ev_m[i].elapsed_time(ev_a[2 * i]) for i in range(args.warmup, args.warmup + args.steps)]
-    res = np.frombuffer(d_res.cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
+    last = (args.warmup + args.steps - 1) & 1
+    res = np.frombuffer(d_res2[last].cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
     assert np.all(res["status"] == 0)
 
     out = None

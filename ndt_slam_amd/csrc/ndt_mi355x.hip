@@ -1282,7 +1282,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       const u64 q0 = wall_clock64();
       compute_region<SSE>(M, L.S.T, scan, n, L);
       const u64 q1 = wall_clock64();
-      float2 *sp = (sorted && !shared_scan) ? sorted + o0 : nullptr;
+      // scratch copy: at the scan's own offsets, or (every match uses scan 0) one slot per workgroup
+      float2 *sp = sorted ? (shared_scan ? sorted + (size_t)blockIdx.x * (size_t)n : sorted + o0) : nullptr;
       if (sort_points<SSE>(M, L.S.T, scan, n, L, pool, sp)) pts = sp;
       const u64 q2 = wall_clock64();
       if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
@@ -1555,7 +1556,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     }
     if (threadIdx.x == 0) L.sflag[2] = (int)ld32(&C->phase);
     __syncthreads();
-    const float2 *pts = L.sflag[1] ? (sorted + o0) : (reinterpret_cast<const float2 *>(scans) + o0);
+    const float2 *pts = L.sflag[1] ? (shared_scan ? sorted + (size_t)(vb % (int)gridDim.x) * (size_t)n : sorted + o0)
+                                   : (reinterpret_cast<const float2 *>(scans) + o0);
     if (L.sflag[2] == 0) fill_window(M, L, pool);          // a scan in its fitness pass needs no window
     const Window W = window_of(L.RG, pool);
     if (prof && threadIdx.x == 0 && prof[8 * vb + 5] == 0) prof[8 * vb + 5] = wall_clock64() - t_start;
@@ -1726,8 +1728,11 @@ struct GridDims { float inv_leaf; int min_bx, min_by, div_x, div_y, gw, gh; };
 
 __device__ __forceinline__ int voxel_of(const GridDims &G, float2 p) {
   if (!finite2(p.x, p.y)) return -1;
-  int ix = (int)floorf(p.x * G.inv_leaf) - G.min_bx;
-  int iy = (int)floorf(p.y * G.inv_leaf) - G.min_by;
+  const float fx = fminf(fmaxf(floorf(p.x * G.inv_leaf), -1.0e9f), 1.0e9f), fy = fminf(fmaxf(floorf(p.y * G.inv_leaf), -1.0e9f), 1.0e9f);
+  const int ix = (int)fx - G.min_bx, iy = (int)fy - G.min_by;
+  // never true for the grid of this cloud's own bounding box; a build queued ahead of the bounding
+  // box read-back with the previous grid (ndt_map_build_dev) must stay inside its buffers
+  if (ix < 0 || ix >= G.div_x || iy < 0 || iy >= G.div_y) return -1;
   return iy * G.div_x + ix;
 }
 
@@ -2041,6 +2046,7 @@ struct ndt_ctx {
   hipStream_t own_stream = nullptr;   // created by ndt_ctx_create
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the last match launch
   hipEvent_t evm0 = nullptr, evm1 = nullptr; // around the last map build
+  hipEvent_t evb = nullptr;                  // bounding box of the map build read back
   bool map_ms_pending = false;
   unsigned *h_bounds = nullptr;              // pinned: bounding box read-back of the map build
   std::string err;
@@ -2075,6 +2081,7 @@ struct ndt_map {
   unsigned *bounds = nullptr; int *counters = nullptr; int *total = nullptr;   // counters: n_cells, n_valid, n_big
   int *big = nullptr; size_t big_cap = 0;
   unsigned *occ = nullptr; size_t occ_cap = 0;
+  GridDims grid; bool have_grid = false;      // voxel grid of the last build (queued ahead of the next one's bounding box)
   void *d_xy_stage = nullptr; size_t d_xy_cap = 0;
 };
 
@@ -2209,6 +2216,7 @@ int ndt_ctx_create(int device, ndt_ctx **out) {
   HIP_TRY(c, hipEventCreate(&c->ev1));
   HIP_TRY(c, hipEventCreate(&c->evm0));
   HIP_TRY(c, hipEventCreate(&c->evm1));
+  HIP_TRY(c, hipEventCreateWithFlags(&c->evb, hipEventDisableTiming));
   HIP_TRY(c, hipHostMalloc((void **)&c->h_bounds, 64, hipHostMallocDefault));
   { int rc = upload_exp_table(c); if (rc) return rc; }
   {
@@ -2235,6 +2243,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->ev1) e = hipEventDestroy(c->ev1);
   if (c->evm0) e = hipEventDestroy(c->evm0);
   if (c->evm1) e = hipEventDestroy(c->evm1);
+  if (c->evb) e = hipEventDestroy(c->evb);
   if (c->h_bounds) e = hipHostFree(c->h_bounds);
   void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_ws};
   for (void *b : bufs) if (b) e = hipFree(b);
@@ -2278,45 +2287,13 @@ int ndt_map_destroy(ndt_map *m) {
   return NDT_OK;
 }
 
-int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, const ndt_params *prm,
-                      ndt_map **pmap) {
-  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
-  if (!xy || n == 0 || !prm || !pmap || !(prm->resolution > 0) || stride < 8 || (stride & 7))
-    return fail(ctx, NDT_E_ARG, "ndt_map_build: bad arguments (need n > 0, resolution > 0, stride % 8 == 0)");
-  if (n > (size_t)INT32_MAX) return fail(ctx, NDT_E_ARG, "ndt_map_build: more than 2^31 points");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+// Steps 2-4 of the map build for a given voxel grid: everything after the bounding box, queued on
+// the context's stream.
+static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size_t stride, const ndt_params *prm,
+                       const GridDims &G) {
   hipStream_t st = ctx->stream;
-  ndt_map *m = *pmap;
-  if (!m) {
-    m = new (std::nothrow) ndt_map();
-    if (!m) return NDT_E_NOMEM;
-    m->ctx = ctx;
-    HIP_TRY(ctx, hipMalloc(&m->bounds, 4 * sizeof(unsigned)));
-    HIP_TRY(ctx, hipMalloc(&m->counters, 4 * sizeof(int)));
-    HIP_TRY(ctx, hipMalloc(&m->total, sizeof(int)));
-    *pmap = m;
-  }
-  m->prm = *prm; m->n = n; m->info_valid = false;
-  HIP_TRY(ctx, hipEventRecord(ctx->evm0, st));
-
-  // 1. bounding box (getMinMax3D)
-  unsigned init_b[4] = {0xffffffffu, 0xffffffffu, 0u, 0u};
-  HIP_TRY(ctx, hipMemcpyAsync(m->bounds, init_b, sizeof(init_b), hipMemcpyHostToDevice, st));
-  map_minmax_kernel<<<grid_for(n, 256 * 16, 512), 256, 0, st>>>(xy, stride, n, m->bounds);
-  unsigned *hb = ctx->h_bounds;                // pinned
-  HIP_TRY(ctx, hipMemcpyAsync(hb, m->bounds, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipStreamSynchronize(st));
-  if (hb[0] == 0xffffffffu) return fail(ctx, NDT_E_ARG, "ndt_map_build: no finite points");
-  const float inv_leaf = 1.0f / prm->resolution;
-  const float mnx = ord2f(hb[0]), mny = ord2f(hb[1]), mxx = ord2f(hb[2]), mxy = ord2f(hb[3]);
-  GridDims G;
-  G.inv_leaf = inv_leaf;
-  G.min_bx = (int)floorf(mnx * inv_leaf); G.min_by = (int)floorf(mny * inv_leaf);
-  long long dx = (long long)(int)floorf(mxx * inv_leaf) - G.min_bx + 1;
-  long long dy = (long long)(int)floorf(mxy * inv_leaf) - G.min_by + 1;
-  if (dx * dy > (1LL << 28)) return fail(ctx, NDT_E_GRID, "ndt_map_build: voxel grid larger than 2^28 cells");
-  G.div_x = (int)dx; G.div_y = (int)dy; G.gw = G.div_x + 4; G.gh = G.div_y + 4;
-  const size_t ng = (size_t)dx * dy, npad = (size_t)G.gw * G.gh;
+  const float inv_leaf = G.inv_leaf;
+  const size_t ng = (size_t)G.div_x * G.div_y, npad = (size_t)G.gw * G.gh;
   m->ng = ng; m->npad = npad;
 
   // 2. buffers (grow-only across rebuilds)
@@ -2363,8 +2340,6 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
                                                                           m->pts, m->cent, m->rec, m->npts_grid,
                                                                           m->counters, m->occ);
   HIP_TRY(ctx, hipGetLastError());
-  HIP_TRY(ctx, hipEventRecord(ctx->evm1, st));
-  ctx->map_ms_pending = true;
 
   MapView &V = m->view;
   V.inv_leaf = inv_leaf; V.leaf = prm->resolution;
@@ -2375,8 +2350,69 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
   gauss_constants(*prm, &V.d1, &V.d2);
   m->info.min_bx = G.min_bx; m->info.min_by = G.min_by; m->info.div_x = G.div_x; m->info.div_y = G.div_y;
   m->info.n_points = n;
+  return NDT_OK;
+}
+
+int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, const ndt_params *prm,
+                      ndt_map **pmap) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!xy || n == 0 || !prm || !pmap || !(prm->resolution > 0) || stride < 8 || (stride & 7))
+    return fail(ctx, NDT_E_ARG, "ndt_map_build: bad arguments (need n > 0, resolution > 0, stride % 8 == 0)");
+  if (n > (size_t)INT32_MAX) return fail(ctx, NDT_E_ARG, "ndt_map_build: more than 2^31 points");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  ndt_map *m = *pmap;
+  if (!m) {
+    m = new (std::nothrow) ndt_map();
+    if (!m) return NDT_E_NOMEM;
+    m->ctx = ctx;
+    HIP_TRY(ctx, hipMalloc(&m->bounds, 4 * sizeof(unsigned)));
+    HIP_TRY(ctx, hipMalloc(&m->counters, 4 * sizeof(int)));
+    HIP_TRY(ctx, hipMalloc(&m->total, sizeof(int)));
+    *pmap = m;
+  }
+  m->prm = *prm; m->n = n; m->info_valid = false;
+  HIP_TRY(ctx, hipEventRecord(ctx->evm0, st));
+
+  // 1. bounding box (getMinMax3D).  The grid follows from it on the host; instead of idling the GPU
+  // during that round trip, the rest of the build is queued at once with the grid of the previous
+  // build of this map (a SLAM local map keeps its voxel bounding box for many scans) and redone
+  // only if the read-back disagrees.
+  unsigned init_b[4] = {0xffffffffu, 0xffffffffu, 0u, 0u};
+  HIP_TRY(ctx, hipMemcpyAsync(m->bounds, init_b, sizeof(init_b), hipMemcpyHostToDevice, st));
+  map_minmax_kernel<<<grid_for(n, 256 * 16, 512), 256, 0, st>>>(xy, stride, n, m->bounds);
+  unsigned *hb = ctx->h_bounds;                // pinned
+  HIP_TRY(ctx, hipMemcpyAsync(hb, m->bounds, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipEventRecord(ctx->evb, st));
+  const float inv_leaf = 1.0f / prm->resolution;
+  bool queued = false;
+  if (m->have_grid && m->grid.inv_leaf == inv_leaf) {
+    int rc = queue_build(ctx, m, xy, n, stride, prm, m->grid);
+    if (rc) return rc;
+    queued = true;
+  }
+  HIP_TRY(ctx, hipEventSynchronize(ctx->evb));
+  if (hb[0] == 0xffffffffu) { m->have_grid = false; return fail(ctx, NDT_E_ARG, "ndt_map_build: no finite points"); }
+  const float mnx = ord2f(hb[0]), mny = ord2f(hb[1]), mxx = ord2f(hb[2]), mxy = ord2f(hb[3]);
+  GridDims G;
+  G.inv_leaf = inv_leaf;
+  G.min_bx = (int)floorf(mnx * inv_leaf); G.min_by = (int)floorf(mny * inv_leaf);
+  long long dx = (long long)(int)floorf(mxx * inv_leaf) - G.min_bx + 1;
+  long long dy = (long long)(int)floorf(mxy * inv_leaf) - G.min_by + 1;
+  if (dx * dy > (1LL << 28)) { m->have_grid = false; return fail(ctx, NDT_E_GRID, "ndt_map_build: voxel grid larger than 2^28 cells"); }
+  G.div_x = (int)dx; G.div_y = (int)dy; G.gw = G.div_x + 4; G.gh = G.div_y + 4;
+  const bool same = queued && G.min_bx == m->grid.min_bx && G.min_by == m->grid.min_by &&
+                    G.div_x == m->grid.div_x && G.div_y == m->grid.div_y;
+  if (!same) {
+    int rc = queue_build(ctx, m, xy, n, stride, prm, G);
+    if (rc) { m->have_grid = false; return rc; }
+  }
+  m->grid = G; m->have_grid = true;
+  HIP_TRY(ctx, hipEventRecord(ctx->evm1, st));
+  ctx->map_ms_pending = true;
   return NDT_OK;                               // asynchronous from here on (stream order)
 }
+
 
 int ndt_map_build(ndt_ctx *ctx, const float *xy_host, size_t n, size_t stride, const ndt_params *prm,
                   ndt_map **pmap) {
@@ -2457,8 +2493,8 @@ int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, co
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   if (st != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->evm1, 0));   // the map build may still be running on the context's stream
   float2 *sorted = nullptr;
-  if (!shared_scan && total_points > 0) {
-    int rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, total_points * 8);
+  if (total_points > 0) {                      // shared scan: one slot of the scan's size per workgroup
+    int rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (shared_scan ? (size_t)ctx->num_cus : (size_t)1) * total_points * 8);
     if (rc) return rc;
     sorted = (float2 *)ctx->d_sorted;
   }
@@ -2499,10 +2535,8 @@ int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, 
   if (want_prof) { HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 128)); HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, (size_t)B * 128, st)); }
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
   float2 *sorted = nullptr;
-  if (!shared_scan) {
-    if ((rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (size_t)offsets[nscan] * 8))) return rc;
-    sorted = (float2 *)ctx->d_sorted;
-  }
+  if ((rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (shared_scan ? (size_t)ctx->num_cus : (size_t)1) * (size_t)offsets[nscan] * 8))) return rc;
+  sorted = (float2 *)ctx->d_sorted;
   if ((rc = launch_align(ctx, map, st, (const float *)ctx->d_scan, (const unsigned long long *)ctx->d_off, B,
                          shared_scan, (const double *)ctx->d_init, (ndt_result *)ctx->d_res, d_trace, trace_cap,
                          d_rows, sorted, d_prof)))
