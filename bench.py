@@ -196,6 +196,30 @@ def main():
             ts.append(e0.elapsed_time(e1))
         out["single_scan_ms"] = float(np.median(ts))
 
+    # Row f1 (source pre-filter, pcl::ApproximateVoxelGrid): raw scans 3x oversampled -> filtered scans,
+    # all on the device; reported beside the headline metric, not part of it (the 10k-pt scans of the
+    # metric are post-filter clouds by definition).
+    if rank == 0 and world == 1 and not args.no_single_scan:
+        rng = np.random.default_rng(11)
+        raw = np.repeat(scans, 3, axis=0) + rng.normal(0, 0.004, (3 * len(scans), 2)).astype(np.float32)
+        raw_off = (off.astype(np.int64) * 3)
+        d_raw = torch.from_numpy(raw).to(dev); d_roff = torch.from_numpy(raw_off).to(dev)
+        d_f = torch.empty_like(d_raw); d_foff = torch.zeros(B + 1, dtype=torch.int64, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(5):
+            e0.record(stream)
+            ctx.prefilter_batch_dev(d_raw.data_ptr(), 8, d_roff.data_ptr(), B, len(raw), 0.05, d_f.data_ptr(),
+                                    d_foff.data_ptr(), stream=stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        n_out = int(d_foff[-1].item())
+        ms = float(np.median(ts))
+        out["prefilter"] = {"scans": B, "raw_points": int(len(raw)), "filtered_points": n_out, "leaf": 0.05, "ms": ms,
+                            "raw_points_per_s": len(raw) / (ms * 1e-3),
+                            "algorithmic_GBps": (len(raw) + n_out) * 8 / (ms * 1e-3) / 1e9}
+
     # CPU baseline: the oracle (a port -- PCL itself is absent) on this box's host cores,
     # rank 0 at N = 1 only, on a bounded sample of the same batch.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -156,6 +156,22 @@ int ndt_eval_at(ndt_ctx *ctx, const ndt_map *map, const float *scan_xy_host, siz
 int ndt_fitness_at(ndt_ctx *ctx, const ndt_map *map, const float *scan_xy_host, size_t n,
                    size_t stride_bytes, float c, float s, float tx, float ty, double *fitness);
 
+/* Replaces the source pre-filter pcl::ApproximateVoxelGrid::filter (src/PoseEstimator.cpp:6-10:
+ * setLeafSize(LeafSize x3), setInputCloud(source_cloud), filter(*filtered_cloud); SURVEY.md 8a row
+ * a1 / 8f row f1) on z = 0 clouds: 512-slot direct-mapped voxel history, flush on collision, the
+ * rest flushed in slot order -- same centroids (float32 sums in cloud order), same output order.
+ * Single scan, host pointers; out_xy_host needs room for n points; *n_out = points written. */
+int ndt_prefilter(ndt_ctx *ctx, const float *xy_host, size_t n, size_t stride_bytes, float leaf,
+                  float *out_xy_host, size_t *n_out);
+/* Batch of B raw scans resident in device memory (points at stride_bytes, raw_offsets[B+1] in
+ * points).  Writes the filtered scans packed as float2 to out_xy_dev (capacity total_raw_points
+ * points) and their offsets[B+1] to out_offsets_dev: exactly the inputs of ndt_align_batch_dev,
+ * whose total_points may be given as total_raw_points (an upper bound).  Asynchronous on `stream`
+ * (NULL = the context's stream). */
+int ndt_prefilter_batch_dev(ndt_ctx *ctx, const float *raw_xy_dev, size_t stride_bytes,
+                            const uint64_t *raw_offsets_dev, int B, size_t total_raw_points, float leaf,
+                            float *out_xy_dev, uint64_t *out_offsets_dev, void *stream);
+
 /* Timing hooks used by bench.py (HIP events on the context's stream; milliseconds of the most
  * recent call of each kind, measured around the kernel launches only). */
 int ndt_last_timing(const ndt_ctx *ctx, float *map_build_ms, float *align_ms);

@@ -48,7 +48,7 @@ EXPORTS = [
     "ndt_ctx_set_stream",
     "ndt_map_build", "ndt_map_build_dev", "ndt_map_destroy", "ndt_map_info_get", "ndt_map_export",
     "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_trace", "ndt_eval_at",
-    "ndt_fitness_at", "ndt_last_timing",
+    "ndt_fitness_at", "ndt_last_timing", "ndt_prefilter", "ndt_prefilter_batch_dev",
 ]
 
 
@@ -82,6 +82,8 @@ def lib():
     L.ndt_eval_at.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp, vp, vp]
     L.ndt_fitness_at.argtypes = [vp, vp, vp, sz, sz, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     L.ndt_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ndt_prefilter.argtypes = [vp, vp, sz, sz, C.c_float, vp, C.POINTER(sz)]
+    L.ndt_prefilter_batch_dev.argtypes = [vp, vp, sz, vp, i, sz, C.c_float, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("ndt_last_error", "ndt_ctx_stream"):
             getattr(L, name).restype = i
@@ -127,6 +129,21 @@ class Context:
     def set_stream(self, stream):
         """Order all work of this context on a caller-owned hipStream_t (int handle or None)."""
         self.check(lib().ndt_ctx_set_stream(self.h, stream), "ndt_ctx_set_stream")
+
+    def prefilter(self, xy, leaf):
+        """pcl::ApproximateVoxelGrid on one scan ([n, 2] float32) -> filtered [m, 2] float32."""
+        xy = _f32c(xy)
+        out = np.empty_like(xy)
+        m = C.c_size_t()
+        self.check(lib().ndt_prefilter(self.h, xy.ctypes.data, len(xy), 8, leaf, out.ctypes.data, C.byref(m)),
+                   "ndt_prefilter")
+        return out[:m.value].copy()
+
+    def prefilter_batch_dev(self, raw_ptr, stride, raw_offsets_ptr, B, total_raw_points, leaf, out_ptr,
+                            out_offsets_ptr, stream=None):
+        """Device pointers in and out (see include/ndt_mi355x.h); asynchronous."""
+        self.check(lib().ndt_prefilter_batch_dev(self.h, raw_ptr, stride, raw_offsets_ptr, B, total_raw_points, leaf,
+                                                 out_ptr, out_offsets_ptr, stream), "ndt_prefilter_batch_dev")
 
     def last_timing(self):
         a, b = C.c_float(), C.c_float()

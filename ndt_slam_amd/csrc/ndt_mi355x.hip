@@ -2034,6 +2034,119 @@ __global__ void fill_f2_kernel(float2 *p, size_t n, float v) {
     p[i] = make_float2(v, v);
 }
 
+
+// ------------------------------------------------------------------------------------------
+// f1: source pre-filter = pcl::ApproximateVoxelGrid::filter on a z = 0 cloud
+// (src/PoseEstimator.cpp:6-10).  The filter is a sequential machine: 512
+// direct-mapped slots, a point either joins the voxel its slot holds or flushes that voxel's
+// centroid to the output and takes the slot; what is left is flushed in slot order at the end.
+// One wave per scan replays it 64 points at a time: lanes whose points hash to different slots
+// update them at once, lanes sharing a slot take turns in point order (the float32 sums of a slot
+// are therefore added in cloud order), and the flushes of a step are written in point order.
+// Output = the reference's output, bit for bit and in the same order.
+// ------------------------------------------------------------------------------------------
+constexpr int kPfSlots = 512;
+__global__ void __launch_bounds__(64)
+prefilter_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
+                 float leaf, float2 *__restrict__ tmp /* at the raw offsets */, unsigned *__restrict__ counts) {
+  __shared__ int s_ix[kPfSlots], s_iy[kPfSlots], s_cnt[kPfSlots];
+  __shared__ float s_cx[kPfSlots], s_cy[kPfSlots];
+  const int lane = threadIdx.x;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const float inv = 1.0f / leaf;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const unsigned long long o0 = offsets[b];
+    const int n = (int)(offsets[b + 1] - o0);
+    for (int h = lane; h < kPfSlots; h += 64) { s_cnt[h] = 0; s_cx[h] = 0.f; s_cy[h] = 0.f; s_ix[h] = 0; s_iy[h] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    int nout = 0;
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const bool active = i < n;
+      float2 p = make_float2(0.f, 0.f);
+      if (active) p = load_pt(xy, stride, (size_t)o0 + (size_t)i);
+      const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
+      const unsigned h = ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);   // iz = 0
+      // lanes of this step that use the same slot, and this lane's turn among them
+      unsigned long long peers = __ballot(active);
+#pragma unroll
+      for (int bit = 0; bit < 9; ++bit) {
+        const unsigned long long one = __ballot(active && ((h >> bit) & 1u));
+        peers &= ((h >> bit) & 1u) ? one : ~one;
+      }
+      const int rank = __builtin_popcountll(peers & lt);
+      bool flushed = false;
+      float fx = 0.f, fy = 0.f;
+      for (int turn = 0; turn < 64; ++turn) {
+        if (!__ballot(active && rank >= turn)) break;
+        if (active && rank == turn) {
+          int cnt = s_cnt[h];
+          float cx = s_cx[h], cy = s_cy[h];
+          if (cnt && (ix != s_ix[h] || iy != s_iy[h])) {     // another voxel holds the slot: flush it
+            flushed = true; fx = cx / (float)cnt; fy = cy / (float)cnt;
+            cnt = 0; cx = 0.f; cy = 0.f;
+          }
+          s_ix[h] = ix; s_iy[h] = iy; s_cnt[h] = cnt + 1;
+          s_cx[h] = cx + p.x; s_cy[h] = cy + p.y;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      const unsigned long long fb = __ballot(flushed);
+      if (flushed) tmp[o0 + (unsigned long long)(nout + __builtin_popcountll(fb & lt))] = make_float2(fx, fy);
+      nout += __builtin_popcountll(fb);
+    }
+    for (int h0 = 0; h0 < kPfSlots; h0 += 64) {              // what is left, in slot order
+      const int h = h0 + lane;
+      const int cnt = s_cnt[h];
+      const unsigned long long fb = __ballot(cnt > 0);
+      if (cnt > 0) tmp[o0 + (unsigned long long)(nout + __builtin_popcountll(fb & lt))] =
+          make_float2(s_cx[h] / (float)cnt, s_cy[h] / (float)cnt);
+      nout += __builtin_popcountll(fb);
+    }
+    if (lane == 0) counts[b] = (unsigned)nout;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// offsets of the filtered scans: exclusive scan of the counts (one workgroup)
+__global__ void __launch_bounds__(1024)
+prefilter_offsets_kernel(const unsigned *__restrict__ counts, int B, unsigned long long *__restrict__ out_offsets) {
+  __shared__ unsigned long long sh[1024];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < B; base += 1024) {
+    const int i = base + threadIdx.x;
+    const unsigned long long v = i < B ? counts[i] : 0ull;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const unsigned long long t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0ull;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < B) out_offsets[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_offsets[B] = carry;
+}
+
+// filtered points from their raw offsets to the packed output
+__global__ void __launch_bounds__(256)
+prefilter_pack_kernel(const float2 *__restrict__ tmp, const unsigned long long *__restrict__ raw_offsets,
+                      const unsigned long long *__restrict__ out_offsets, int B, float2 *__restrict__ out) {
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const unsigned long long r0 = raw_offsets[b], q0 = out_offsets[b];
+    const unsigned long long n = out_offsets[b + 1] - q0;
+    for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < n;
+         j += (unsigned long long)gridDim.x * blockDim.x)
+      out[q0 + j] = tmp[r0 + j];
+  }
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -2061,6 +2174,7 @@ struct ndt_ctx {
   void *d_rows = nullptr; size_t d_rows_cap = 0;
   void *d_sorted = nullptr; size_t d_sorted_cap = 0;   // per-lane ordered copy of the scans
   void *d_ws = nullptr; size_t d_ws_cap = 0;           // WsHeader + ScanCtl[B] + chunk totals
+  void *d_pf = nullptr; size_t d_pf_cap = 0;           // pre-filter: filtered points at the raw offsets + counts
   int num_cus = 0;
   int helpers = 1;                                     // NDT_NO_HELPERS=1 disables work sharing (diagnostic)
 };
@@ -2245,7 +2359,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->evm1) e = hipEventDestroy(c->evm1);
   if (c->evb) e = hipEventDestroy(c->evb);
   if (c->h_bounds) e = hipHostFree(c->h_bounds);
-  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_ws};
+  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_ws, c->d_pf};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
   delete c;
@@ -2669,6 +2783,56 @@ int ndt_fitness_at(ndt_ctx *ctx, const ndt_map *map, const float *scan, size_t n
   for (int b = 0; b < grid; ++b) { sum += hp[2 * b]; cnt += hp[2 * b + 1]; }
   free(hp);
   *fitness = cnt > 0 ? sum / cnt : DBL_MAX;
+  return NDT_OK;
+}
+
+int ndt_prefilter_batch_dev(ndt_ctx *ctx, const float *raw_xy, size_t stride, const uint64_t *raw_offsets, int B,
+                            size_t total_raw_points, float leaf, float *out_xy, uint64_t *out_offsets, void *stream) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!raw_xy || !raw_offsets || !out_xy || !out_offsets || B <= 0 || total_raw_points == 0 || !(leaf > 0) ||
+      stride < 8 || (stride & 7))
+    return fail(ctx, NDT_E_ARG, "ndt_prefilter_batch: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  int rc;
+  // filtered points at the raw offsets, then the per-scan counts
+  const size_t tmp_bytes = total_raw_points * sizeof(float2);
+  if ((rc = ensure(ctx, &ctx->d_pf, &ctx->d_pf_cap, tmp_bytes + (size_t)B * sizeof(unsigned)))) return rc;
+  float2 *tmp = (float2 *)ctx->d_pf;
+  unsigned *counts = (unsigned *)((char *)ctx->d_pf + tmp_bytes);
+  const int grid = B < 8 * ctx->num_cus ? B : 8 * ctx->num_cus;
+  prefilter_kernel<<<grid, 64, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf, tmp, counts);
+  prefilter_offsets_kernel<<<1, 1024, 0, st>>>(counts, B, (unsigned long long *)out_offsets);
+  const int gx = (int)std::min<size_t>(64, (total_raw_points / (size_t)B + 255) / 256 + 1);
+  prefilter_pack_kernel<<<dim3((unsigned)gx, (unsigned)std::min(B, 65535)), 256, 0, st>>>(
+      tmp, (const unsigned long long *)raw_offsets, (const unsigned long long *)out_offsets, B, (float2 *)out_xy);
+  HIP_TRY(ctx, hipGetLastError());
+  return NDT_OK;
+}
+
+int ndt_prefilter(ndt_ctx *ctx, const float *xy_host, size_t n, size_t stride, float leaf, float *out_xy_host,
+                  size_t *n_out) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!xy_host || n == 0 || !out_xy_host || !n_out || stride < 8 || (stride & 7) || !(leaf > 0))
+    return fail(ctx, NDT_E_ARG, "ndt_prefilter: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  if ((rc = ensure(ctx, &ctx->d_scan, &ctx->d_scan_cap, n * stride + n * sizeof(float2)))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_off, &ctx->d_off_cap, 4 * sizeof(uint64_t)))) return rc;
+  float *d_in = (float *)ctx->d_scan;
+  float *d_out = (float *)((char *)ctx->d_scan + n * stride);
+  uint64_t *d_offs = (uint64_t *)ctx->d_off;                  // [0..1] raw, [2..3] filtered
+  const uint64_t raw[2] = {0, (uint64_t)n};
+  HIP_TRY(ctx, hipMemcpyAsync(d_in, xy_host, n * stride, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_offs, raw, sizeof(raw), hipMemcpyHostToDevice, st));
+  if ((rc = ndt_prefilter_batch_dev(ctx, d_in, stride, d_offs, 1, n, leaf, d_out, d_offs + 2, st))) return rc;
+  uint64_t fo[2] = {0, 0};
+  HIP_TRY(ctx, hipMemcpyAsync(fo, d_offs + 2, sizeof(fo), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  *n_out = (size_t)fo[1];
+  HIP_TRY(ctx, hipMemcpyAsync(out_xy_host, d_out, (size_t)fo[1] * sizeof(float2), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
   return NDT_OK;
 }
 

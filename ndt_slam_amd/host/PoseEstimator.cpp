@@ -79,8 +79,11 @@ double PoseEstimator::estimatePose(Pose2D &initPose, Pose2D &estPose, Matrix3d &
   const double kFailed = 10000000;                                   // src/PoseEstimator.cpp:45
   for (double &c : cov) c = std::numeric_limits<double>::quiet_NaN();
   if (!ctx_ || !target_ || target_->empty() || source_.empty()) return kFailed;
-  // :6-10  approximate voxel filter of the source cloud
-  const std::vector<float> filtered = approximateVoxelGrid(source_, (float)LeafSize_);
+  // :6-10  approximate voxel filter of the source cloud, on the device
+  std::vector<float> filtered(source_.size());
+  size_t nf = 0;
+  if (ndt_prefilter(ctx_, source_.data(), source_.size() / 2, 8, (float)LeafSize_, filtered.data(), &nf) != NDT_OK) return kFailed;
+  filtered.resize(2 * nf);
   // :17-19 setInputSource / setInputTarget -- the target is rebuilt on every call, as the
   // reference does (its local map is refilled in place each scan, src/PointCloudMap.cpp:119-131)
   if (ndt_map_build(ctx_, &(*target_)[0].x, target_->size(), sizeof(PointXYZ), &prm_, &map_) != NDT_OK) return kFailed;

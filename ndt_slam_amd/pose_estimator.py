@@ -54,7 +54,7 @@ class Scan2D:
 def approximate_voxel_grid(xy32, leaf):
     """pcl::ApproximateVoxelGrid::filter on a z = 0 cloud (src/PoseEstimator.cpp:6-10;
     SURVEY.md 8a row a1): 512-slot direct-mapped history, flush on collision, order dependent.
-    Stays on the host side of the boundary."""
+    Host restatement kept for the tests; estimatePose uses the device filter (ndt_prefilter, row f1)."""
     xy32 = np.ascontiguousarray(xy32, dtype=np.float32)
     inv = np.float32(1.0) / np.float32(leaf)
     ix = np.floor(xy32[:, 0] * inv).astype(np.int64)
@@ -104,7 +104,7 @@ class PoseEstimator:
 
     def estimatePose(self, initPose):
         """src/PoseEstimator.cpp:4-69.  Returns (cost, estPose, cov)."""
-        filtered = approximate_voxel_grid(self.source_cloud, self.LeafSize)        # :6-10
+        filtered = self.ctx.prefilter(self.source_cloud, self.LeafSize)             # :6-10, on the device (f1)
         # :17-19 -- the target is rebuilt on every call, as the reference does (the local map is
         # refilled in place each scan, src/PointCloudMap.cpp:119-131)
         if self._map is None:
