@@ -740,6 +740,9 @@ constexpr int kWaves = kBlock / 64;
 constexpr int kSub = 4;                      // a lane's points are cut into kSub runs -> kSub units per wave
 constexpr int kUnits = kWaves * kSub;        // units per pass
 constexpr int kMaxHelpers = 15;              // helper workgroups per scan, hard limit (64 units: 4 each)
+#ifndef NDT_IDLE_MAX
+#define NDT_IDLE_MAX 800           // idle helper back-off: 4 us doubling up to 8 us (100 MHz ticks)
+#endif
 #ifndef NDT_HELPER_PENALTY
 #define NDT_HELPER_PENALTY 12    // passes a scan must be ahead by before it gets one more helper than another
 #endif
@@ -1291,15 +1294,9 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         unsigned *gw = wantmap + (size_t)b * (kRegionCells / 32);
         for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) gw[i] = wmap[i];
       }
-      fill_window(M, L, pool);
-      const u64 q3 = wall_clock64();
-      if (prof && threadIdx.x == 0) {
-        const u64 q4 = wall_clock64();
-        prof[8 * (size_t)B + 8 * (size_t)b + 6] = ((q1 - q0) << 32) | ((q2 - q1) & 0xFFFFFFFFull);
-        prof[8 * (size_t)B + 8 * (size_t)b + 7] = ((q3 - q2) << 32) | ((u64)(L.diag[0] & 0xFFFFu) << 16) | (u64)(L.diag[1] & 0xFFFFu);
-      }
       if (allow_helpers) {
-        // publish geometry + ordered copy: plain stores, drained by every wave, then one agent release
+        // publish geometry + marked cells + ordered copy before staging the own window, so that idle
+        // workgroups stage theirs meanwhile: plain stores, drained by every wave, then one agent release
         if (threadIdx.x == 0) {
           const Region r = L.RG;
           C->region[0] = r.x0; C->region[1] = r.y0; C->region[2] = r.rw; C->region[3] = r.rh;
@@ -1313,6 +1310,13 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
           drain_vmem();
           st64(&C->ticket, (u64)1 << 32);                     // epoch 1: open for joining, nothing to compute (h = 0)
         }
+      }
+      fill_window(M, L, pool);
+      const u64 q3 = wall_clock64();
+      if (prof && threadIdx.x == 0) {
+        const u64 q4 = wall_clock64();
+        prof[8 * (size_t)B + 8 * (size_t)b + 6] = ((q1 - q0) << 32) | ((q2 - q1) & 0xFFFFFFFFull);
+        prof[8 * (size_t)B + 8 * (size_t)b + 7] = ((q3 - q2) << 32) | ((u64)(L.diag[0] & 0xFFFFu) << 16) | (u64)(L.diag[1] & 0xFFFFu);
       }
     }
     const Window W = window_of(L.RG, pool);
@@ -1427,24 +1431,29 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         ubeg = uend;
       }
       if (aborted) break;
-      // pass total = sum of the unit totals in unit order
-      if (threadIdx.x < 12) {
-        double sum = 0.0;
-        for (int v = 0; v < kUnits; ++v) sum += L.wpart[v * 12 + threadIdx.x];
-        L.tot[threadIdx.x] = sum;
+      // pass total: the units in four groups of 16, each summed in unit order by one lane per value,
+      // then the four partial sums in order; wave 0 goes straight on to the optimiser step
+      static_assert(kUnits == 64, "four groups of 16 units");
+      if (threadIdx.x < 64) {
+        const int j = lane % 12, grp = lane / 12;             // lanes 48..63: nothing to add
+        double part = 0.0;
+        if (lane < 48) for (int v = 16 * grp; v < 16 * grp + 16; ++v) part += L.wpart[v * 12 + j];
+        const double p1 = __shfl(part, j + 12), p2 = __shfl(part, j + 24), p3 = __shfl(part, j + 36);
+        if (lane < 12) L.tot[lane] = ((part + p1) + p2) + p3;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (prof) { tt1 = wall_clock64(); }
+        if (!fit_pass && lane == 0) advance(L.S, P, M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
       }
-      __syncthreads();
-      if (prof) { tt1 = wall_clock64(); t_eval += tt1 - tt0; if (fit_pass) t_fit = tt1 - tt0; }
-      if (!fit_pass) {
-        if (threadIdx.x == 0) advance(L.S, P, M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
-        // meanwhile another wave fetches the number of registered helpers for the next pass
-        if (threadIdx.x == 64 && allow_helpers) L.sflag[1] = (int)rd32_fresh(&C->ready);
-      } else {
-        fitness_done = true;
-      }
+      // meanwhile another wave fetches the number of registered helpers for the next pass
+      if (!fit_pass && threadIdx.x == 64 && allow_helpers) L.sflag[1] = (int)rd32_fresh(&C->ready);
+      if (fit_pass) fitness_done = true;
       __syncthreads();
       if (prof) {
         const u64 te = wall_clock64();
+        if (threadIdx.x >= 64) tt1 = te;          // (only wave 0 stamps the end of the summation)
+        t_eval += tt1 - tt0; if (fit_pass) t_fit = tt1 - tt0;
         t_adv += te - tt1;
         if (pass_h > 0 && !fit_pass) { a_pro += ts1 - tt0; a_own += ts2 - ts1; a_wait += ts3 - ts2; a_comb += tt1 - ts3; a_adv += te - tt1; a_n += 1; }
       }
@@ -1526,10 +1535,10 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         }
       }
       L.sflag[3] = code;
-      if (code == -1) {                                    // back off: 4 us, doubling up to ~64 us
+      if (code == -1) {                                    // back off: 4 us, doubling up to NDT_IDLE_MAX ticks
         const u64 t0 = wall_clock64();
         while (wall_clock64() - t0 < idle_ticks) __builtin_amdgcn_s_sleep(64);
-        if (idle_ticks < 6400) idle_ticks *= 2;
+        if (idle_ticks < NDT_IDLE_MAX) idle_ticks *= 2;
       } else {
         idle_ticks = 400;
       }
