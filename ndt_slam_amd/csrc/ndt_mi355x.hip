@@ -746,7 +746,10 @@ constexpr int kMaxHelpers = 15;              // helper workgroups per scan, hard
 #ifndef NDT_HELPER_PENALTY
 #define NDT_HELPER_PENALTY 12    // passes a scan must be ahead by before it gets one more helper than another
 #endif
-constexpr int kBaseHelpers = 7;              // ... while more scans are unfinished than workgroups / 8
+#ifndef NDT_BASE_HELPERS
+#define NDT_BASE_HELPERS 7
+#endif
+constexpr int kBaseHelpers = NDT_BASE_HELPERS;              // ... while more scans are unfinished than workgroups / 8
 constexpr unsigned kEpochDone = 0xFFFFFFFFu;
 constexpr unsigned long long kWatchTicks = 400000000ull;   // ~4 s of the 100 MHz wall clock
 
@@ -1338,7 +1341,6 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       // closed as soon as a helper has registered, so that the rest of the pass is shared.
       int pass_h = 0, ubeg = 0;
       bool pose_out = false;                       // thread 0: pose block of this pass is in the control block
-      const u64 t_pass0 = wall_clock64();
       for (int seg = 0; seg <= kUnits && ubeg < kUnits; ++seg) {
         if (threadIdx.x == 0) {
           if (seg == 0) {
@@ -1385,10 +1387,10 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
             if (u >= kUnits) break;
             unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, u % kWaves, u / kWaves, u / kWaves + 1, L.wpart + u * 12, 0);
             if (watch && wave == kWaves - 1 && lane == 0) {
-              // one wave looks for a registered helper between its units; a pass that has been running
-              // for 100 us with more than half of it to go asks for one
+              // one wave looks for a registered helper between its units.  (Raising the scan's priority
+              // when this pass runs long was tried: it draws helpers away from the scans that still have
+              // tens of passes to go and cost 5 % of the batch rate.)
               if (ld32(&C->ready) > 0u) L.stop = 1;
-              else if (u < kUnits / 2 && wall_clock64() - t_pass0 > 10000) st32(&C->passes, 150u);
             }
           }
           if (watch) {                                       // units [ubeg, ubeg + claimed) are done
