@@ -719,20 +719,22 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
 //
 // One workgroup per CU.  Every scan has an OWNER workgroup that holds the optimiser state in LDS
 // and runs the whole match on the device.  A derivative pass (and the fitness pass) is cut into
-// chunks of kChunkPts points; each chunk is reduced on its own and the pass total is the sum of
-// the chunk totals in chunk order, so the result does not depend on who computed which chunk.
+// kUnits units of points; each unit is reduced on its own and the pass total is the sum of the
+// unit totals in a fixed order, so the result does not depend on who computed which unit.
 // A workgroup whose own scans are finished becomes a HELPER: it attaches to an unfinished scan,
-// stages that scan's window in its own LDS and claims chunks of that scan's passes.  Matches
-// differ widely in the number of passes they need (mean ~12, max ~40 on the bench workload), so
-// without helpers most of the chip idles behind the slowest scans.
+// stages that scan's window in its own LDS, registers, and from then on computes its static share
+// of the units of every pass the owner opens.  Matches differ widely in the number of passes they
+// need (mean ~12, max ~40 on the bench workload), so without helpers most of the chip idles
+// behind the slowest scans.
 //
-// Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16): every shared word (ticket,
-// arrival counter, pose block, chunk totals) is read and written ONLY with agent-scope relaxed
-// atomics (sc1 loads / write-through stores), payload stores are drained (s_waitcnt vmcnt(0))
-// before the word that signals them, and the one bulk hand-off (the owner's ordered scan copy and
-// window geometry) uses plain stores + agent release fence on the owner and an agent acquire
-// fence on the helper.  No workgroup ever waits for a specific other workgroup to be scheduled:
-// owners only wait for chunks that some running workgroup has already claimed, helpers only poll.
+// Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16): every shared word (epoch word,
+// arrival counter, ready counter, pose block, unit totals) is read and written ONLY with
+// agent-scope relaxed atomics (sc1 loads / write-through stores), payload stores are drained
+// (s_waitcnt vmcnt(0)) before the word that signals them, and the one bulk hand-off (the owner's
+// ordered scan copy, marked-cell bitmap and window geometry) uses plain stores + agent release
+// fence on the owner and an agent acquire fence on the helper.  No workgroup ever waits for a
+// workgroup that is not running: a helper is only counted in after it has registered, at which
+// point it does nothing but poll the scan's epoch word; helpers themselves only poll.
 // Every spin is bounded by a watchdog that raises the abort word.
 // ------------------------------------------------------------------------------------------
 constexpr int kBlock = 1024;
