@@ -777,13 +777,14 @@ struct alignas(128) ScanCtl {
   u32 ready;         //         helpers whose window is staged; rank = order of registration
   u32 phase;         //         1: the scan is in its fitness pass (a helper needs no window)
   u32 use_sorted;    //         1: passes read the scan from the sorted scratch copy
-  int pad2_[21];
+  u32 owner_wg;      //         workgroup that owns the scan (its scratch slot when every match uses scan 0)
+  int pad2_[20];
   u64 pose[6];       // line 3: float32 transform (c|s, tx|ty) and the four fp64 angle terms
   u64 pad3_[10];
 };
 static_assert(sizeof(ScanCtl) == 512, "ScanCtl is four 128-byte lines");
 
-struct WsHeader { u32 done; u32 abort; u32 pad[30]; };
+struct WsHeader { u32 done; u32 abort; u32 next; u32 pad[29]; };   // next: scans handed out beyond the first gridDim.x
 static_assert(sizeof(WsHeader) == 128, "WsHeader");
 
 #define NDT_RLX __ATOMIC_RELAXED
@@ -1270,7 +1271,9 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
   bool aborted = false;
 
   // =========================== owner of scans blockIdx.x, + gridDim.x, ... ===========================
-  for (int b = blockIdx.x; b < B && !aborted; b += gridDim.x) {
+  // scans are taken from a queue: the first gridDim.x by workgroup number, the rest in the order
+  // workgroups become free (results do not depend on who owns which scan)
+  for (int b = blockIdx.x; b < B && !aborted;) {
     const u64 o0 = shared_scan ? offsets[0] : offsets[b];
     const u64 o1 = shared_scan ? offsets[1] : offsets[b + 1];
     const int n = (int)(o1 - o0);
@@ -1307,6 +1310,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
           C->region[0] = r.x0; C->region[1] = r.y0; C->region[2] = r.rw; C->region[3] = r.rh;
           C->region[4] = r.cap; C->region[5] = r.nspill;
           C->use_sorted = (pts != scan) ? 1u : 0u;
+          C->owner_wg = blockIdx.x;
         }
         drain_vmem();
         __syncthreads();
@@ -1495,6 +1499,11 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         p2[0] = a_n; p2[1] = a_pro; p2[2] = a_own; p2[3] = a_wait; p2[4] = a_comb; p2[5] = a_adv;
       }
     }
+      // next scan of the batch, if any
+    __syncthreads();
+    if (threadIdx.x == 0) L.sflag[3] = (int)gridDim.x + (int)__hip_atomic_fetch_add(&hdr->next, 1u, NDT_RLX, NDT_AGENT);
+    __syncthreads();
+    b = L.sflag[3];
   }
 
   // ============================================ helper ============================================
@@ -1556,7 +1565,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     const u64 o0 = shared_scan ? offsets[0] : offsets[vb];
     const u64 o1 = shared_scan ? offsets[1] : offsets[vb + 1];
     const int n = (int)(o1 - o0);
-    if (threadIdx.x == 0) L.sflag[1] = (int)C->use_sorted;
+    if (threadIdx.x == 0) { L.sflag[1] = (int)C->use_sorted; L.sflag[0] = (int)C->owner_wg; }
     if (threadIdx.x == 0) {
       Region r; r.x0 = C->region[0]; r.y0 = C->region[1]; r.rw = C->region[2]; r.rh = C->region[3];
       r.cap = C->region[4]; r.nspill = C->region[5];
@@ -1569,7 +1578,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     }
     if (threadIdx.x == 0) L.sflag[2] = (int)ld32(&C->phase);
     __syncthreads();
-    const float2 *pts = L.sflag[1] ? (shared_scan ? sorted + (size_t)(vb % (int)gridDim.x) * (size_t)n : sorted + o0)
+    const int owner_wg = L.sflag[0];
+    const float2 *pts = L.sflag[1] ? (shared_scan ? sorted + (size_t)owner_wg * (size_t)n : sorted + o0)
                                    : (reinterpret_cast<const float2 *>(scans) + o0);
     if (L.sflag[2] == 0) fill_window(M, L, pool);          // a scan in its fitness pass needs no window
     const Window W = window_of(L.RG, pool);
