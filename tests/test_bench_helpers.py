@@ -1,0 +1,26 @@
+"""CPU checks of bench.py's bookkeeping (the bench itself needs a GPU)."""
+import json
+import os
+
+import numpy as np
+
+import bench
+
+
+def test_algorithmic_bytes_follow_survey_8d():
+    res = np.zeros(2, dtype=[("evals", "i4"), ("kbar", "f8")])
+    res["evals"] = [10, 20]; res["kbar"] = [2.0, 3.0]
+    n = 1000
+    want = 10 * n * (8 + 20 * 2.0) + 16 * n + 20 * n * (8 + 20 * 3.0) + 16 * n
+    assert bench.algorithmic_bytes(res, n) == want
+
+
+def test_traffic_summary_is_consistent_with_the_pmc_files():
+    traffic, src = bench.measured_traffic()
+    root = os.path.dirname(os.path.abspath(bench.__file__))
+    if traffic is None:
+        assert not os.path.isdir(os.path.join(root, "profiles")) or not [f for f in os.listdir(os.path.join(root, "profiles")) if f.endswith("_traffic.json")]
+        return
+    t = json.load(open(os.path.join(root, src)))
+    assert traffic == (t["fetch_size_kb"] + t["write_size_kb"]) * 1024.0
+    assert 1e6 < traffic < 1e11
