@@ -172,6 +172,35 @@ int ndt_prefilter_batch_dev(ndt_ctx *ctx, const float *raw_xy_dev, size_t stride
                             const uint64_t *raw_offsets_dev, int B, size_t total_raw_points, float leaf,
                             float *out_xy_dev, uint64_t *out_offsets_dev, void *stream);
 
+/* SURVEY.md 8f row f2 -- the steps either side of the match, for a batch resident in device
+ * memory.  Poses are (tx, ty, th) triples of doubles with th in DEGREES (include/ndt_slam/Pose2D.h:14);
+ * covariances are row-major 3x3 in (m, m, rad). */
+typedef struct ndt_fuse_params {
+  double coe_ndt_cov;  /* include/ndt_slam/PoseEstimator.h:63  coeNDTCov  (1.0) */
+  double coe_vel;      /* include/ndt_slam/PoseFuser.h:19      coeVel     (0.1) */
+  double coe_omega;    /* include/ndt_slam/PoseFuser.h:19      coeOmega   (0.1) */
+  double del_time;     /* include/ndt_slam/PoseFuser.h:19      delTime    (0.5) */
+  double score_thre;   /* include/ndt_slam/ScanMatcher.h:49-50 scthre     (0.0; launch file sets score_thre) */
+} ndt_fuse_params;
+int ndt_fuse_default_params(ndt_fuse_params *p);
+/* Replaces Pose2D::calMotion (src/Pose2D.cpp:5-16) + Pose2D::calPredPose (:28-37) as
+ * ScanMatcher::matchScan chains them (src/ScanMatcher.cpp:27-32): odometry motion in the robot
+ * frame, predicted pose, and (if init_xyyaw_dev != NULL) the same pose as the (tx, ty, yaw[rad])
+ * guess ndt_align_batch_dev takes.  All arrays B x 3 doubles in device memory; asynchronous. */
+int ndt_predict_batch_dev(ndt_ctx *ctx, const double *odo_cur_dev, const double *odo_prev_dev,
+                          const double *last_pose_dev, int B, double *odo_motion_dev, double *pred_pose_dev,
+                          double *init_xyyaw_dev, void *stream);
+/* Replaces, per match: cost with the 1e7 sentinel and Qmat = (-H)^-1 * coeNDTCov
+ * (src/PoseEstimator.cpp:43-64), the accept test cost <= scthre (src/ScanMatcher.cpp:50), then
+ * PoseFuser::fusePose (src/PoseFuser.cpp:3-37) or, for a rejected match, the predicted pose with
+ * PoseFuser::calOdometryCovariance (src/PoseFuser.cpp:39-61; src/ScanMatcher.cpp:60-66).
+ * results_dev: B records as written by ndt_align_batch_dev; last_cov_dev, cov_dev: B x 9;
+ * successful_dev: B ints or NULL.  Asynchronous on `stream`. */
+int ndt_fuse_batch_dev(ndt_ctx *ctx, const ndt_result *results_dev, const double *pred_pose_dev,
+                       const double *odo_motion_dev, const double *last_pose_dev, const double *last_cov_dev,
+                       int B, const ndt_fuse_params *prm, double *fused_pose_dev, double *cov_dev,
+                       int *successful_dev, void *stream);
+
 /* Timing hooks used by bench.py (HIP events on the context's stream; milliseconds of the most
  * recent call of each kind, measured around the kernel launches only). */
 int ndt_last_timing(const ndt_ctx *ctx, float *map_build_ms, float *align_ms);

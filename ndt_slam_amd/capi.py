@@ -30,6 +30,12 @@ class Params(C.Structure):
     ]
 
 
+class FuseParams(C.Structure):
+    """ndt_fuse_params (include/ndt_mi355x.h)."""
+    _fields_ = [("coe_ndt_cov", C.c_double), ("coe_vel", C.c_double), ("coe_omega", C.c_double),
+                ("del_time", C.c_double), ("score_thre", C.c_double)]
+
+
 class MapInfo(C.Structure):
     _fields_ = [("min_bx", C.c_int), ("min_by", C.c_int), ("div_x", C.c_int), ("div_y", C.c_int),
                 ("n_cells", C.c_int), ("n_valid", C.c_int), ("n_points", C.c_size_t)]
@@ -49,6 +55,7 @@ EXPORTS = [
     "ndt_map_build", "ndt_map_build_dev", "ndt_map_destroy", "ndt_map_info_get", "ndt_map_export",
     "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_trace", "ndt_eval_at",
     "ndt_fitness_at", "ndt_last_timing", "ndt_prefilter", "ndt_prefilter_batch_dev",
+    "ndt_fuse_default_params", "ndt_predict_batch_dev", "ndt_fuse_batch_dev",
 ]
 
 
@@ -84,6 +91,9 @@ def lib():
     L.ndt_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ndt_prefilter.argtypes = [vp, vp, sz, sz, C.c_float, vp, C.POINTER(sz)]
     L.ndt_prefilter_batch_dev.argtypes = [vp, vp, sz, vp, i, sz, C.c_float, vp, vp, vp]
+    L.ndt_fuse_default_params.argtypes = [C.POINTER(FuseParams)]
+    L.ndt_predict_batch_dev.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp]
+    L.ndt_fuse_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, i, C.POINTER(FuseParams), vp, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("ndt_last_error", "ndt_ctx_stream"):
             getattr(L, name).restype = i
@@ -94,6 +104,16 @@ def lib():
 def default_params(**kw):
     p = Params()
     lib().ndt_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def default_fuse_params(**kw):
+    p = FuseParams()
+    lib().ndt_fuse_default_params(C.byref(p))
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)
@@ -144,6 +164,19 @@ class Context:
         """Device pointers in and out (see include/ndt_mi355x.h); asynchronous."""
         self.check(lib().ndt_prefilter_batch_dev(self.h, raw_ptr, stride, raw_offsets_ptr, B, total_raw_points, leaf,
                                                  out_ptr, out_offsets_ptr, stream), "ndt_prefilter_batch_dev")
+
+    def predict_batch_dev(self, odo_cur_ptr, odo_prev_ptr, last_pose_ptr, B, motion_ptr, pred_ptr, init_ptr=None,
+                          stream=None):
+        """Row f2, before the match: device pointers to B x 3 doubles (degrees); asynchronous."""
+        self.check(lib().ndt_predict_batch_dev(self.h, odo_cur_ptr, odo_prev_ptr, last_pose_ptr, B, motion_ptr, pred_ptr,
+                                               init_ptr, stream), "ndt_predict_batch_dev")
+
+    def fuse_batch_dev(self, results_ptr, pred_ptr, motion_ptr, last_pose_ptr, last_cov_ptr, B, prm, fused_ptr, cov_ptr,
+                       successful_ptr=None, stream=None):
+        """Row f2, after the match: device pointers; asynchronous."""
+        self.check(lib().ndt_fuse_batch_dev(self.h, results_ptr, pred_ptr, motion_ptr, last_pose_ptr, last_cov_ptr, B,
+                                            C.byref(prm), fused_ptr, cov_ptr, successful_ptr, stream),
+                   "ndt_fuse_batch_dev")
 
     def last_timing(self):
         a, b = C.c_float(), C.c_float()

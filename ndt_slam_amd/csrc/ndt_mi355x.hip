@@ -2170,6 +2170,149 @@ prefilter_pack_kernel(const float2 *__restrict__ tmp, const unsigned long long *
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// f2: the steps either side of the match for a batch -- odometry prediction (Pose2D::calMotion +
+// calPredPose, src/Pose2D.cpp:5-37, chained as in src/ScanMatcher.cpp:27-32) and, after the
+// match, cost / NDT covariance (src/PoseEstimator.cpp:43-64), the accept test
+// (src/ScanMatcher.cpp:50) and the EKF fusion or the odometry covariance alone
+// (src/PoseFuser.cpp:3-61).  One lane per match, fp64, the oracle's expression order.
+// Poses are (tx, ty, th) with th in degrees (include/ndt_slam/Pose2D.h:14).
+// ------------------------------------------------------------------------------------------
+struct FuseParams { double coe_ndt_cov, coe_vel, coe_omega, del_time, score_thre; };
+__device__ __forceinline__ double f2_deg2rad(double x) { return x * M_PI / 180; }
+__device__ __forceinline__ double f2_rad2deg(double x) { return x * 180 / M_PI; }
+__device__ __forceinline__ double f2_add_angle(double a1, double a2) {
+  double sum = a1 + a2;
+  if (sum < -180) sum += 360; else if (sum >= 180) sum -= 360;
+  return sum;
+}
+__device__ __forceinline__ double f2_sub_angle(double a1, double a2) {
+  double dif = a1 - a2;
+  if (dif < -180) dif += 360; else if (dif >= 180) dif -= 360;
+  return dif;
+}
+__device__ __forceinline__ void f2_inv3(const double m[9], double out[9]) {   // Eigen's fixed 3x3 inverse
+  const double c00 = m[4] * m[8] - m[5] * m[7];
+  const double c10 = m[2] * m[7] - m[1] * m[8];
+  const double c20 = m[1] * m[5] - m[2] * m[4];
+  const double det = c00 * m[0] + c10 * m[3] + c20 * m[6];
+  const double id = 1.0 / det;
+  out[0] = c00 * id; out[1] = c10 * id; out[2] = c20 * id;
+  out[3] = (m[5] * m[6] - m[3] * m[8]) * id;
+  out[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+  out[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  out[6] = (m[3] * m[7] - m[4] * m[6]) * id;
+  out[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+  out[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+__device__ __forceinline__ void f2_mul3(const double a[9], const double b[9], double o[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double s = a[3 * i] * b[j];
+      s += a[3 * i + 1] * b[3 + j];
+      s += a[3 * i + 2] * b[6 + j];
+      o[3 * i + j] = s;
+    }
+}
+__device__ __forceinline__ void f2_odo_cov(const double motion[3], const double last[3], const double last_cov[9],
+                                           const FuseParams &p, double cov[9]) {
+  const double dt = p.del_time;
+  const double v = sqrt(motion[0] * motion[0] + motion[1] * motion[1]) / dt;
+  const double omega = f2_deg2rad(motion[2] / dt);
+  const double m00 = p.coe_vel * v * v, m11 = p.coe_omega * omega * omega;
+  const double a = f2_deg2rad(last[2]), c = cos(a), s = sin(a);
+  const double F[9] = {1, 0, -v * dt * s, 0, 1, v * dt * c, 0, 0, 1};
+  const double Ft[9] = {1, 0, 0, 0, 1, 0, F[2], F[5], 1};
+  double t[9], flf[9];
+  f2_mul3(F, last_cov, t); f2_mul3(t, Ft, flf);
+  const double a0 = dt * c, a1 = dt * s;
+  const double ama[9] = {a0 * m00 * a0, a0 * m00 * a1, 0, a1 * m00 * a0, a1 * m00 * a1, 0, 0, 0, dt * m11 * dt};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) cov[i] = flf[i] + ama[i];
+}
+
+__global__ void __launch_bounds__(256)
+predict_kernel(const double *__restrict__ odo_cur, const double *__restrict__ odo_prev,
+               const double *__restrict__ last_pose, int B, double *__restrict__ motion_out,
+               double *__restrict__ pred_out, double *__restrict__ init_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double *cur = odo_cur + 3 * b, *prev = odo_prev + 3 * b, *last = last_pose + 3 * b;
+  const double ap = f2_deg2rad(prev[2]), cp = cos(ap), sp = sin(ap);
+  const double dx = cur[0] - prev[0], dy = cur[1] - prev[1];
+  double motion[3];
+  motion[0] = cp * dx + sp * dy;
+  motion[1] = -sp * dx + cp * dy;
+  motion[2] = f2_sub_angle(cur[2], prev[2]);
+  const double al = f2_deg2rad(last[2]), cl = cos(al), sl = sin(al);
+  double pred[3];
+  pred[0] = cl * motion[0] + -sl * motion[1] + last[0];
+  pred[1] = sl * motion[0] + cl * motion[1] + last[1];
+  pred[2] = f2_add_angle(last[2], motion[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { motion_out[3 * b + i] = motion[i]; pred_out[3 * b + i] = pred[i]; }
+  if (init_out) {                               // the guess ndt_align takes (src/PoseEstimator.cpp:22-24)
+    init_out[3 * b] = pred[0]; init_out[3 * b + 1] = pred[1]; init_out[3 * b + 2] = f2_deg2rad(pred[2]);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+fuse_kernel(const ndt_result *__restrict__ res, const double *__restrict__ pred_pose,
+            const double *__restrict__ odo_motion, const double *__restrict__ last_pose,
+            const double *__restrict__ last_cov, int B, FuseParams p, double *__restrict__ fused_out,
+            double *__restrict__ cov_out, int *__restrict__ successful_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const ndt_result r = res[b];
+  double pred[3], motion[3], last[3], lc[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { pred[i] = pred_pose[3 * b + i]; motion[i] = odo_motion[3 * b + i]; last[i] = last_pose[3 * b + i]; }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) lc[i] = last_cov[9 * b + i];
+  const double est[3] = {r.pose[0], r.pose[1], f2_rad2deg(r.pose[2])};
+  const double cost = (r.status == NDT_OK && r.converged) ? r.fitness : 10000000.0;
+  const int successful = cost <= p.score_thre;
+  double fused[3], cov[9];
+  if (!successful) {
+    f2_odo_cov(motion, last, lc, p, cov);
+    fused[0] = pred[0]; fused[1] = pred[1]; fused[2] = pred[2];
+  } else {
+    double nh[9], Q[9], ch[9], sum[9], inv[9], K[9], imk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nh[i] = -r.H[i];
+    f2_inv3(nh, Q);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Q[i] *= p.coe_ndt_cov;
+    f2_odo_cov(motion, last, lc, p, ch);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sum[i] = Q[i] + ch[i];
+    f2_inv3(sum, inv);
+    f2_mul3(ch, inv, K);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) imk[i] = ((i % 4 == 0) ? 1.0 : 0.0) - K[i];
+    f2_mul3(imk, ch, cov);
+    const double zh[3] = {est[0] - pred[0], est[1] - pred[1], f2_deg2rad(f2_sub_angle(est[2], pred[2]))};
+    const double mu_hat[3] = {pred[0], pred[1], f2_deg2rad(pred[2])};
+    double mu[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double s = K[3 * i] * zh[0];
+      s += K[3 * i + 1] * zh[1];
+      s += K[3 * i + 2] * zh[2];
+      mu[i] = s + mu_hat[i];
+    }
+    fused[0] = mu[0]; fused[1] = mu[1]; fused[2] = f2_rad2deg(mu[2]);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) fused_out[3 * b + i] = fused[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) cov_out[9 * b + i] = cov[i];
+  if (successful_out) successful_out[b] = successful;
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -2856,6 +2999,40 @@ int ndt_prefilter(ndt_ctx *ctx, const float *xy_host, size_t n, size_t stride, f
   *n_out = (size_t)fo[1];
   HIP_TRY(ctx, hipMemcpyAsync(out_xy_host, d_out, (size_t)fo[1] * sizeof(float2), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
+  return NDT_OK;
+}
+
+int ndt_fuse_default_params(ndt_fuse_params *p) {
+  if (!p) return NDT_E_ARG;
+  p->coe_ndt_cov = 1.0; p->coe_vel = 0.1; p->coe_omega = 0.1; p->del_time = 0.5; p->score_thre = 0.0;
+  return NDT_OK;
+}
+
+int ndt_predict_batch_dev(ndt_ctx *ctx, const double *odo_cur, const double *odo_prev, const double *last_pose, int B,
+                          double *odo_motion, double *pred_pose, double *init_xyyaw, void *stream) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!odo_cur || !odo_prev || !last_pose || !odo_motion || !pred_pose || B <= 0)
+    return fail(ctx, NDT_E_ARG, "ndt_predict_batch: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  predict_kernel<<<(B + 255) / 256, 256, 0, st>>>(odo_cur, odo_prev, last_pose, B, odo_motion, pred_pose, init_xyyaw);
+  HIP_TRY(ctx, hipGetLastError());
+  return NDT_OK;
+}
+
+int ndt_fuse_batch_dev(ndt_ctx *ctx, const ndt_result *results, const double *pred_pose, const double *odo_motion,
+                       const double *last_pose, const double *last_cov, int B, const ndt_fuse_params *prm,
+                       double *fused_pose, double *cov, int *successful, void *stream) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!results || !pred_pose || !odo_motion || !last_pose || !last_cov || !prm || !fused_pose || !cov || B <= 0 ||
+      !(prm->del_time > 0))
+    return fail(ctx, NDT_E_ARG, "ndt_fuse_batch: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  FuseParams P = {prm->coe_ndt_cov, prm->coe_vel, prm->coe_omega, prm->del_time, prm->score_thre};
+  fuse_kernel<<<(B + 255) / 256, 256, 0, st>>>(results, pred_pose, odo_motion, last_pose, last_cov, B, P, fused_pose,
+                                               cov, successful);
+  HIP_TRY(ctx, hipGetLastError());
   return NDT_OK;
 }
 

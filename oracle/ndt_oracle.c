@@ -778,3 +778,123 @@ size_t ndt_oracle_approx_voxel_filter(const float *xy, size_t n, size_t stride, 
   }
   return op;
 }
+
+
+/* ------------------------------------------------------------------------------------------
+ * odometry prediction and EKF fusion around the match.
+ * ------------------------------------------------------------------------------------------ */
+#define F2_DEG2RAD(x) ((x) * M_PI / 180)     /* include/ndt_slam/MyUtil.h:22 */
+#define F2_RAD2DEG(x) ((x) * 180 / M_PI)     /* include/ndt_slam/MyUtil.h:23 */
+
+void ndt_oracle_fuse_default_params(ndt_oracle_fuse_params *p) {
+  p->coe_ndt_cov = 1.0; p->coe_vel = 0.1; p->coe_omega = 0.1; p->del_time = 0.5; p->score_thre = 0.0;
+}
+
+static double f2_add_angle(double a1, double a2) {   /* src/MyUtil.cpp:4-12 */
+  double sum = a1 + a2;
+  if (sum < -180) sum += 360; else if (sum >= 180) sum -= 360;
+  return sum;
+}
+static double f2_sub_angle(double a1, double a2) {   /* src/MyUtil.cpp:15-23 */
+  double dif = a1 - a2;
+  if (dif < -180) dif += 360; else if (dif >= 180) dif -= 360;
+  return dif;
+}
+
+void ndt_oracle_predict(const double cur[3], const double prev[3], const double last[3],
+                        double motion[3], double pred[3]) {
+  /* Pose2D::calRmat of prevPose / lastPose (include/ndt_slam/Pose2D.h:43-48) */
+  double ap = F2_DEG2RAD(prev[2]), cp = cos(ap), sp = sin(ap);
+  double dx = cur[0] - prev[0], dy = cur[1] - prev[1];
+  motion[0] = cp * dx + sp * dy;                    /* Rmat[0][0]*dx + Rmat[1][0]*dy */
+  motion[1] = -sp * dx + cp * dy;                   /* Rmat[0][1]*dx + Rmat[1][1]*dy */
+  motion[2] = f2_sub_angle(cur[2], prev[2]);
+  double al = F2_DEG2RAD(last[2]), cl = cos(al), sl = sin(al);
+  pred[0] = cl * motion[0] + -sl * motion[1] + last[0];
+  pred[1] = sl * motion[0] + cl * motion[1] + last[1];
+  pred[2] = f2_add_angle(last[2], motion[2]);
+}
+
+/* Eigen's fixed-size 3x3 inverse (include/Eigen/src/LU/InverseImpl.h:140-200): cofactors, the
+ * determinant along column 0, everything multiplied by 1/det. */
+static void f2_inv3(const double m[9], double out[9]) {
+#define M(i, j) m[3 * (i) + (j)]
+  double c00 = M(1,1) * M(2,2) - M(1,2) * M(2,1);
+  double c10 = M(0,2) * M(2,1) - M(0,1) * M(2,2);     /* cofactor<1,0> */
+  double c20 = M(0,1) * M(1,2) - M(0,2) * M(1,1);
+  double det = c00 * M(0,0) + c10 * M(1,0) + c20 * M(2,0);
+  double id = 1.0 / det;
+  out[0] = c00 * id; out[1] = c10 * id; out[2] = c20 * id;
+  out[3] = (M(1,2) * M(2,0) - M(1,0) * M(2,2)) * id;
+  out[4] = (M(0,0) * M(2,2) - M(0,2) * M(2,0)) * id;
+  out[5] = (M(0,2) * M(1,0) - M(0,0) * M(1,2)) * id;
+  out[6] = (M(1,0) * M(2,1) - M(1,1) * M(2,0)) * id;
+  out[7] = (M(0,1) * M(2,0) - M(0,0) * M(2,1)) * id;
+  out[8] = (M(0,0) * M(1,1) - M(0,1) * M(1,0)) * id;
+#undef M
+}
+static void f2_mul3(const double a[9], const double b[9], double o[9]) {
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      double s = a[3 * i] * b[j];
+      s += a[3 * i + 1] * b[3 + j];
+      s += a[3 * i + 2] * b[6 + j];
+      o[3 * i + j] = s;
+    }
+}
+
+/* PoseFuser::calOdometryCovariance (src/PoseFuser.cpp:39-61) */
+static void f2_odo_cov(const double motion[3], const double last[3], const double last_cov[9],
+                       const ndt_oracle_fuse_params *p, double cov[9]) {
+  double dt = p->del_time;
+  double v = sqrt(motion[0] * motion[0] + motion[1] * motion[1]) / dt;   /* Pose2D::calDistance */
+  double omega = F2_DEG2RAD(motion[2] / dt);
+  double m00 = p->coe_vel * v * v, m11 = p->coe_omega * omega * omega;
+  double a = F2_DEG2RAD(last[2]), c = cos(a), s = sin(a);
+  double F[9] = {1, 0, -v * dt * s, 0, 1, v * dt * c, 0, 0, 1};
+  double Ft[9] = {1, 0, 0, 0, 1, 0, F[2], F[5], 1};
+  double t[9], flf[9];
+  f2_mul3(F, last_cov, t); f2_mul3(t, Ft, flf);
+  /* A M A^T with A = [dt c, 0; dt s, 0; 0, dt] */
+  double a0 = dt * c, a1 = dt * s;
+  double ama[9] = {a0 * m00 * a0, a0 * m00 * a1, 0, a1 * m00 * a0, a1 * m00 * a1, 0, 0, 0, dt * m11 * dt};
+  for (int i = 0; i < 9; ++i) cov[i] = flf[i] + ama[i];
+}
+
+int ndt_oracle_fuse(const ndt_oracle_result *r, const double pred[3], const double motion[3],
+                    const double last[3], const double last_cov[9], const ndt_oracle_fuse_params *p,
+                    double fused[3], double cov[9]) {
+  /* src/PoseEstimator.cpp:29-36,43-46: estimated pose in degrees, cost with the 1e7 sentinel */
+  double est[3] = {r->pose[0], r->pose[1], F2_RAD2DEG(r->pose[2])};
+  double cost = r->converged ? r->fitness : 10000000.0;
+  int successful = cost <= p->score_thre;             /* src/ScanMatcher.cpp:50 */
+  if (!successful) {                                  /* :63-65 */
+    f2_odo_cov(motion, last, last_cov, p, cov);
+    fused[0] = pred[0]; fused[1] = pred[1]; fused[2] = pred[2];
+    return 0;
+  }
+  /* src/PoseEstimator.cpp:57-64: Qmat = (-H3)^-1 * coeNDTCov */
+  double nh[9], Q[9];
+  for (int i = 0; i < 9; ++i) nh[i] = -r->H[i];
+  f2_inv3(nh, Q);
+  for (int i = 0; i < 9; ++i) Q[i] *= p->coe_ndt_cov;
+  /* PoseFuser::fusePose (src/PoseFuser.cpp:3-37) */
+  double ch[9], sum[9], inv[9], K[9], imk[9];
+  f2_odo_cov(motion, last, last_cov, p, ch);
+  for (int i = 0; i < 9; ++i) sum[i] = Q[i] + ch[i];
+  f2_inv3(sum, inv);
+  f2_mul3(ch, inv, K);
+  for (int i = 0; i < 9; ++i) imk[i] = ((i % 4 == 0) ? 1.0 : 0.0) - K[i];
+  f2_mul3(imk, ch, cov);
+  double zh[3] = {est[0] - pred[0], est[1] - pred[1], F2_DEG2RAD(f2_sub_angle(est[2], pred[2]))};
+  double mu_hat[3] = {pred[0], pred[1], F2_DEG2RAD(pred[2])};
+  double mu[3];
+  for (int i = 0; i < 3; ++i) {
+    double s = K[3 * i] * zh[0];
+    s += K[3 * i + 1] * zh[1];
+    s += K[3 * i + 2] * zh[2];
+    mu[i] = s + mu_hat[i];
+  }
+  fused[0] = mu[0]; fused[1] = mu[1]; fused[2] = F2_RAD2DEG(mu[2]);
+  return 1;
+}

@@ -140,6 +140,28 @@ void ndt_oracle_gauss(const ndt_oracle_params *prm, double *d1, double *d2);
 /* 3x3 symmetric pseudo-inverse solve H x = b (stands in for the 6x6 JacobiSVD solve). */
 void ndt_oracle_solve3(const double H[9], const double b[3], double x[3]);
 
+/* ---- the steps either side of the match (also parity unpinned: the
+ * reference's own sources need ROS + Eigen headers, absent here; restated from src/Pose2D.cpp,
+ * src/PoseFuser.cpp, src/MyUtil.cpp:4-23, src/ScanMatcher.cpp:27-67, src/PoseEstimator.cpp:43-64).
+ * Poses are (tx, ty, th) with th in DEGREES as in include/ndt_slam/Pose2D.h:14. ---- */
+typedef struct ndt_oracle_fuse_params {
+  double coe_ndt_cov;  /* PoseEstimator.h:63 coeNDTCov (1.0)  */
+  double coe_vel;      /* PoseFuser.h:19 coeVel (0.1)         */
+  double coe_omega;    /* PoseFuser.h:19 coeOmega (0.1)       */
+  double del_time;     /* PoseFuser.h:19 delTime (0.5)        */
+  double score_thre;   /* ScanMatcher.h:49 scthre (0.0, launch file: score_thre) */
+} ndt_oracle_fuse_params;
+void ndt_oracle_fuse_default_params(ndt_oracle_fuse_params *p);
+/* Pose2D::calMotion (src/Pose2D.cpp:5-16) then Pose2D::calPredPose (:28-37), as ScanMatcher::matchScan
+ * chains them (src/ScanMatcher.cpp:27-32): odometry motion in the robot frame and the predicted pose. */
+void ndt_oracle_predict(const double odo_cur[3], const double odo_prev[3], const double last_pose[3],
+                        double motion[3], double pred[3]);
+/* src/PoseEstimator.cpp:43-64 (cost, Qmat from the Hessian), src/ScanMatcher.cpp:50-67 (decision),
+ * PoseFuser::fusePose / calOdometryCovariance (src/PoseFuser.cpp:3-61).  Returns `successful`. */
+int ndt_oracle_fuse(const ndt_oracle_result *r, const double pred[3], const double motion[3],
+                    const double last_pose[3], const double last_cov[9],
+                    const ndt_oracle_fuse_params *prm, double fused[3], double cov[9]);
+
 #ifdef __cplusplus
 }
 #endif

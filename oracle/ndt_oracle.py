@@ -200,3 +200,38 @@ def mt_update(a_l, f_l, g_l, a_u, f_u, g_u, a_t, f_t, g_t):
     v = [C.c_double(x) for x in (a_l, f_l, g_l, a_u, f_u, g_u)]
     r = lib().ndt_oracle_mt_update(*[C.byref(x) for x in v], a_t, f_t, g_t)
     return r, [x.value for x in v]
+
+
+# ---- SURVEY.md 8f row f2 (oracle/ndt_oracle.h) ----
+class FuseParams(C.Structure):
+    _fields_ = [("coe_ndt_cov", C.c_double), ("coe_vel", C.c_double), ("coe_omega", C.c_double),
+                ("del_time", C.c_double), ("score_thre", C.c_double)]
+
+
+def default_fuse_params(**kw):
+    p = FuseParams()
+    lib().ndt_oracle_fuse_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def predict(odo_cur, odo_prev, last_pose):
+    """-> (motion[3], pred[3]); poses (tx, ty, th_deg)."""
+    a = [(C.c_double * 3)(*np.asarray(v, float)) for v in (odo_cur, odo_prev, last_pose)]
+    motion, pred = (C.c_double * 3)(), (C.c_double * 3)()
+    lib().ndt_oracle_predict(a[0], a[1], a[2], motion, pred)
+    return np.array(motion), np.array(pred)
+
+
+def fuse(result, pred, motion, last_pose, last_cov, prm):
+    """result: one record of the result dtype (numpy) -> (successful, fused[3], cov[3,3])."""
+    r = Result()
+    C.memmove(C.addressof(r), np.ascontiguousarray(result).tobytes(), C.sizeof(Result))
+    a = [(C.c_double * 3)(*np.asarray(v, float)) for v in (pred, motion, last_pose)]
+    lc = (C.c_double * 9)(*np.asarray(last_cov, float).ravel())
+    fused, cov = (C.c_double * 3)(), (C.c_double * 9)()
+    ok = lib().ndt_oracle_fuse(C.byref(r), a[0], a[1], a[2], lc, C.byref(prm), fused, cov)
+    return int(ok), np.array(fused), np.array(cov).reshape(3, 3)
