@@ -201,6 +201,20 @@ int ndt_fuse_batch_dev(ndt_ctx *ctx, const ndt_result *results_dev, const double
                        int B, const ndt_fuse_params *prm, double *fused_pose_dev, double *cov_dev,
                        int *successful_dev, void *stream);
 
+/* SURVEY.md 8f row f3 (part) -- replaces PCFilter::remove_neighborPoint(cloud_base, point_list)
+ * (include/ndt_slam/PCFilter.h:29-56, called from Submap::makeMap, src/PointCloudMap.cpp:27): the points
+ * of `base` with no point of `list` closer than thre_neighbor (PCLUtil::distance_points' float32
+ * distance, include/ndt_slam/PCLUtil.h:21-23, strict <), in input order, packed as float2.
+ * out needs room for n_base points; n_list may be 0.  (PCFilter::difference_extraction, the PCL octree
+ * change detector that produces `list`, stays with PCL.) */
+int ndt_remove_neighbors(ndt_ctx *ctx, const float *base_xy_host, size_t base_stride_bytes, size_t n_base,
+                         const float *list_xy_host, size_t list_stride_bytes, size_t n_list, double thre_neighbor,
+                         float *out_xy_host, size_t *n_out);
+/* Same with device pointers; *n_out_dev is a uint64 in device memory; asynchronous on `stream`. */
+int ndt_remove_neighbors_dev(ndt_ctx *ctx, const float *base_xy_dev, size_t base_stride_bytes, size_t n_base,
+                             const float *list_xy_dev, size_t list_stride_bytes, size_t n_list,
+                             double thre_neighbor, float *out_xy_dev, uint64_t *n_out_dev, void *stream);
+
 /* Timing hooks used by bench.py (HIP events on the context's stream; milliseconds of the most
  * recent call of each kind, measured around the kernel launches only). */
 int ndt_last_timing(const ndt_ctx *ctx, float *map_build_ms, float *align_ms);

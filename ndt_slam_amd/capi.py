@@ -56,6 +56,7 @@ EXPORTS = [
     "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_trace", "ndt_eval_at",
     "ndt_fitness_at", "ndt_last_timing", "ndt_prefilter", "ndt_prefilter_batch_dev",
     "ndt_fuse_default_params", "ndt_predict_batch_dev", "ndt_fuse_batch_dev",
+    "ndt_remove_neighbors", "ndt_remove_neighbors_dev",
 ]
 
 
@@ -94,6 +95,8 @@ def lib():
     L.ndt_fuse_default_params.argtypes = [C.POINTER(FuseParams)]
     L.ndt_predict_batch_dev.argtypes = [vp, vp, vp, vp, i, vp, vp, vp, vp]
     L.ndt_fuse_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, i, C.POINTER(FuseParams), vp, vp, vp, vp]
+    L.ndt_remove_neighbors.argtypes = [vp, vp, sz, sz, vp, sz, sz, C.c_double, vp, C.POINTER(sz)]
+    L.ndt_remove_neighbors_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, C.c_double, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("ndt_last_error", "ndt_ctx_stream"):
             getattr(L, name).restype = i
@@ -164,6 +167,17 @@ class Context:
         """Device pointers in and out (see include/ndt_mi355x.h); asynchronous."""
         self.check(lib().ndt_prefilter_batch_dev(self.h, raw_ptr, stride, raw_offsets_ptr, B, total_raw_points, leaf,
                                                  out_ptr, out_offsets_ptr, stream), "ndt_prefilter_batch_dev")
+
+    def remove_neighbors(self, base, point_list, thre_neighbor):
+        """PCFilter::remove_neighborPoint: base points with no list point within thre_neighbor, in order."""
+        base = _f32c(base)
+        lst = np.ascontiguousarray(point_list, dtype=np.float32).reshape(-1, 2)
+        out = np.empty_like(base)
+        m = C.c_size_t()
+        self.check(lib().ndt_remove_neighbors(self.h, base.ctypes.data, 8, len(base), lst.ctypes.data if len(lst) else None,
+                                              8, len(lst), thre_neighbor, out.ctypes.data, C.byref(m)),
+                   "ndt_remove_neighbors")
+        return out[:m.value].copy()
 
     def predict_batch_dev(self, odo_cur_ptr, odo_prev_ptr, last_pose_ptr, B, motion_ptr, pred_ptr, init_ptr=None,
                           stream=None):

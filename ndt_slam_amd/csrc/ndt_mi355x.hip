@@ -2313,6 +2313,89 @@ fuse_kernel(const ndt_result *__restrict__ res, const double *__restrict__ pred_
   if (successful_out) successful_out[b] = successful;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// f3 (part): PCFilter::remove_neighborPoint (include/ndt_slam/PCFilter.h:29-56) -- keep the points
+// of `base` that have no point of `list` closer than thre_neighbor, in input order.  The
+// reference tests every pair (O(n*m) on the CPU, the largest cost outside NDT when moving
+// objects are removed, src/PointCloudMap.cpp:15-39); here one lane per base point walks the list
+// through LDS tiles.  The distance is PCLUtil::distance_points' float32 expression
+// (include/ndt_slam/PCLUtil.h:21-23) compared with the double threshold, so the kept set is
+// identical; a ballot prefix keeps the order.
+// ------------------------------------------------------------------------------------------
+constexpr int kRnBlock = 256, kRnTile = 1024;
+__device__ __forceinline__ bool rn_near(float2 p, float2 q, double thre) {
+  const float dx = p.x - q.x, dy = p.y - q.y;
+  const float d2 = dx * dx + dy * dy;            // (+ dz*dz with dz = 0 adds nothing)
+  return (double)sqrtf(d2) < thre;
+}
+__global__ void __launch_bounds__(kRnBlock)
+remove_neighbors_flag_kernel(const float *__restrict__ base, size_t bstride, int nb, const float *__restrict__ list,
+                             size_t lstride, int nl, double thre, unsigned char *__restrict__ keep,
+                             int *__restrict__ block_count) {
+  __shared__ float2 tile[kRnTile];
+  __shared__ int wsum[kRnBlock / 64];
+  const int i = blockIdx.x * kRnBlock + threadIdx.x;
+  float2 p = make_float2(0.f, 0.f);
+  if (i < nb) p = load_pt(base, bstride, (size_t)i);
+  bool flag = i < nb;
+  for (int t0 = 0; t0 < nl; t0 += kRnTile) {
+    const int m = min(kRnTile, nl - t0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < m; j += kRnBlock) tile[j] = load_pt(list, lstride, (size_t)(t0 + j));
+    __syncthreads();
+    if (flag) {                                   // (the reference keeps testing; the outcome is the same)
+      bool near = false;
+      for (int j = 0; j < m; ++j) near = near || rn_near(p, tile[j], thre);
+      flag = !near;
+    }
+  }
+  if (i < nb) keep[i] = flag ? 1 : 0;
+  const unsigned long long b = __ballot(flag);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __builtin_popcountll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) { int s = 0; for (int w = 0; w < kRnBlock / 64; ++w) s += wsum[w]; block_count[blockIdx.x] = s; }
+}
+// exclusive scan of the block counts (one workgroup), total to *n_out
+__global__ void __launch_bounds__(1024)
+remove_neighbors_scan_kernel(int *__restrict__ block_count, int nblocks, unsigned long long *__restrict__ n_out) {
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblocks ? block_count[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblocks) block_count[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_out = (unsigned long long)carry;
+}
+__global__ void __launch_bounds__(kRnBlock)
+remove_neighbors_pack_kernel(const float *__restrict__ base, size_t bstride, int nb, const unsigned char *__restrict__ keep,
+                             const int *__restrict__ block_off, float2 *__restrict__ out) {
+  __shared__ int wsum[kRnBlock / 64];
+  const int i = blockIdx.x * kRnBlock + threadIdx.x;
+  const bool flag = i < nb && keep[i];
+  const unsigned long long b = __ballot(flag);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wsum[wv] = __builtin_popcountll(b);
+  __syncthreads();
+  int off = block_off[blockIdx.x];
+  for (int w = 0; w < wv; ++w) off += wsum[w];
+  if (flag) out[off + __builtin_popcountll(b & ((1ull << lane) - 1ull))] = load_pt(base, bstride, (size_t)i);
+}
+
 }  // namespace
 
 // ==========================================================================================
@@ -2341,6 +2424,7 @@ struct ndt_ctx {
   void *d_sorted = nullptr; size_t d_sorted_cap = 0;   // per-lane ordered copy of the scans
   void *d_ws = nullptr; size_t d_ws_cap = 0;           // WsHeader + ScanCtl[B] + chunk totals
   void *d_pf = nullptr; size_t d_pf_cap = 0;           // pre-filter: filtered points at the raw offsets + counts
+  void *d_rn = nullptr; size_t d_rn_cap = 0;           // neighbour removal: block offsets + keep flags
   int num_cus = 0;
   int helpers = 1;                                     // NDT_NO_HELPERS=1 disables work sharing (diagnostic)
 };
@@ -2525,7 +2609,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->evm1) e = hipEventDestroy(c->evm1);
   if (c->evb) e = hipEventDestroy(c->evb);
   if (c->h_bounds) e = hipHostFree(c->h_bounds);
-  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_ws, c->d_pf};
+  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_ws, c->d_pf, c->d_rn};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
   delete c;
@@ -3033,6 +3117,57 @@ int ndt_fuse_batch_dev(ndt_ctx *ctx, const ndt_result *results, const double *pr
   fuse_kernel<<<(B + 255) / 256, 256, 0, st>>>(results, pred_pose, odo_motion, last_pose, last_cov, B, P, fused_pose,
                                                cov, successful);
   HIP_TRY(ctx, hipGetLastError());
+  return NDT_OK;
+}
+
+int ndt_remove_neighbors_dev(ndt_ctx *ctx, const float *base_xy, size_t base_stride, size_t n_base, const float *list_xy,
+                             size_t list_stride, size_t n_list, double thre_neighbor, float *out_xy, uint64_t *n_out,
+                             void *stream) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!base_xy || n_base == 0 || n_base > (size_t)INT32_MAX || n_list > (size_t)INT32_MAX || (n_list && !list_xy) ||
+      !out_xy || !n_out || base_stride < 8 || (base_stride & 7) || (n_list && (list_stride < 8 || (list_stride & 7))))
+    return fail(ctx, NDT_E_ARG, "ndt_remove_neighbors: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  const int nblocks = (int)((n_base + kRnBlock - 1) / kRnBlock);
+  int rc;
+  if ((rc = ensure(ctx, &ctx->d_rn, &ctx->d_rn_cap, n_base + (size_t)nblocks * sizeof(int) + 16))) return rc;
+  int *block_count = (int *)ctx->d_rn;
+  unsigned char *keep = (unsigned char *)ctx->d_rn + (size_t)nblocks * sizeof(int);
+  remove_neighbors_flag_kernel<<<nblocks, kRnBlock, 0, st>>>(base_xy, base_stride, (int)n_base, list_xy, list_stride,
+                                                             (int)n_list, thre_neighbor, keep, block_count);
+  remove_neighbors_scan_kernel<<<1, 1024, 0, st>>>(block_count, nblocks, (unsigned long long *)n_out);
+  remove_neighbors_pack_kernel<<<nblocks, kRnBlock, 0, st>>>(base_xy, base_stride, (int)n_base, keep, block_count,
+                                                             (float2 *)out_xy);
+  HIP_TRY(ctx, hipGetLastError());
+  return NDT_OK;
+}
+
+int ndt_remove_neighbors(ndt_ctx *ctx, const float *base_xy_host, size_t base_stride, size_t n_base,
+                         const float *list_xy_host, size_t list_stride, size_t n_list, double thre_neighbor,
+                         float *out_xy_host, size_t *n_out) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!base_xy_host || n_base == 0 || !out_xy_host || !n_out || (n_list && !list_xy_host))
+    return fail(ctx, NDT_E_ARG, "ndt_remove_neighbors: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  const size_t bb = n_base * base_stride, lb = n_list * list_stride, ob = n_base * sizeof(float2);
+  if ((rc = ensure(ctx, &ctx->d_scan, &ctx->d_scan_cap, bb + lb + ob + 64))) return rc;
+  char *d = (char *)ctx->d_scan;
+  float *d_base = (float *)d, *d_list = (float *)(d + bb), *d_out = (float *)(d + bb + ((lb + 15) & ~(size_t)15));
+  if ((rc = ensure(ctx, &ctx->d_off, &ctx->d_off_cap, 4 * sizeof(uint64_t)))) return rc;
+  HIP_TRY(ctx, hipMemcpyAsync(d_base, base_xy_host, bb, hipMemcpyHostToDevice, st));
+  if (n_list) HIP_TRY(ctx, hipMemcpyAsync(d_list, list_xy_host, lb, hipMemcpyHostToDevice, st));
+  if ((rc = ndt_remove_neighbors_dev(ctx, d_base, base_stride, n_base, n_list ? d_list : nullptr, n_list ? list_stride : 8,
+                                     n_list, thre_neighbor, d_out, (uint64_t *)ctx->d_off, st)))
+    return rc;
+  uint64_t cnt = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&cnt, ctx->d_off, sizeof(cnt), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  *n_out = (size_t)cnt;
+  HIP_TRY(ctx, hipMemcpyAsync(out_xy_host, d_out, (size_t)cnt * sizeof(float2), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
   return NDT_OK;
 }
 

@@ -898,3 +898,19 @@ int ndt_oracle_fuse(const ndt_oracle_result *r, const double pred[3], const doub
   fused[0] = mu[0]; fused[1] = mu[1]; fused[2] = F2_RAD2DEG(mu[2]);
   return 1;
 }
+
+
+/* SURVEY.md 8f row f3 (part) */
+size_t ndt_oracle_remove_neighbors(const float *base, size_t nb, const float *list, size_t nl, double thre, float *out) {
+  size_t cnt = 0;
+  for (size_t i = 0; i < nb; ++i) {
+    int flag = 1;
+    for (size_t j = 0; j < nl; ++j) {
+      float dx = base[2 * i] - list[2 * j], dy = base[2 * i + 1] - list[2 * j + 1], dz = 0.0f - 0.0f;
+      float d2 = dx * dx + dy * dy + dz * dz;
+      if ((double)sqrtf(d2) < thre) flag = 0;
+    }
+    if (flag) { out[2 * cnt] = base[2 * i]; out[2 * cnt + 1] = base[2 * i + 1]; ++cnt; }
+  }
+  return cnt;
+}

@@ -162,6 +162,12 @@ int ndt_oracle_fuse(const ndt_oracle_result *r, const double pred[3], const doub
                     const double last_pose[3], const double last_cov[9],
                     const ndt_oracle_fuse_params *prm, double fused[3], double cov[9]);
 
+/* PCFilter::remove_neighborPoint (include/ndt_slam/PCFilter.h:29-56) with
+ * PCLUtil::distance_points (include/ndt_slam/PCLUtil.h:21-23) on z = 0 clouds: all pairs, float32
+ * distance, strict <, input order kept.  out_xy must hold 2*n_base floats; returns the count. */
+size_t ndt_oracle_remove_neighbors(const float *base_xy, size_t n_base, const float *list_xy, size_t n_list,
+                                   double thre_neighbor, float *out_xy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -235,3 +235,15 @@ def fuse(result, pred, motion, last_pose, last_cov, prm):
     fused, cov = (C.c_double * 3)(), (C.c_double * 9)()
     ok = lib().ndt_oracle_fuse(C.byref(r), a[0], a[1], a[2], lc, C.byref(prm), fused, cov)
     return int(ok), np.array(fused), np.array(cov).reshape(3, 3)
+
+
+def remove_neighbors(base, point_list, thre_neighbor):
+    """SURVEY.md 8f row f3 (part): PCFilter::remove_neighborPoint."""
+    base = _f32c(base)
+    lst = np.ascontiguousarray(point_list, dtype=np.float32).reshape(-1, 2)
+    out = np.zeros_like(base)
+    L = lib()
+    L.ndt_oracle_remove_neighbors.restype = C.c_size_t
+    L.ndt_oracle_remove_neighbors.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]
+    n = L.ndt_oracle_remove_neighbors(base.ctypes.data, len(base), lst.ctypes.data, len(lst), thre_neighbor, out.ctypes.data)
+    return out[:n].copy()
