@@ -2069,25 +2069,27 @@ __global__ void fill_f2_kernel(float2 *p, size_t n, float v) {
 // Output = the reference's output, bit for bit and in the same order.
 // ------------------------------------------------------------------------------------------
 constexpr int kPfSlots = 512;
+struct __attribute__((aligned(8))) PfSlot { int ix, iy, cnt; float cx, cy; int pad; };   // 24 B: one b128 + one b64 LDS read
 __global__ void __launch_bounds__(64)
 prefilter_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
                  float leaf, float2 *__restrict__ tmp /* at the raw offsets */, unsigned *__restrict__ counts) {
-  __shared__ int s_ix[kPfSlots], s_iy[kPfSlots], s_cnt[kPfSlots];
-  __shared__ float s_cx[kPfSlots], s_cy[kPfSlots];
+  __shared__ PfSlot slot[kPfSlots];
   const int lane = threadIdx.x;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const float inv = 1.0f / leaf;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const unsigned long long o0 = offsets[b];
     const int n = (int)(offsets[b + 1] - o0);
-    for (int h = lane; h < kPfSlots; h += 64) { s_cnt[h] = 0; s_cx[h] = 0.f; s_cy[h] = 0.f; s_ix[h] = 0; s_iy[h] = 0; }
+    for (int h = lane; h < kPfSlots; h += 64) { PfSlot z; z.ix = 0; z.iy = 0; z.cnt = 0; z.cx = 0.f; z.cy = 0.f; z.pad = 0; slot[h] = z; }
     __builtin_amdgcn_wave_barrier();
     int nout = 0;
+    float2 pnext = make_float2(0.f, 0.f);
+    if (lane < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)lane);
     for (int base = 0; base < n; base += 64) {
       const int i = base + lane;
       const bool active = i < n;
-      float2 p = make_float2(0.f, 0.f);
-      if (active) p = load_pt(xy, stride, (size_t)o0 + (size_t)i);
+      const float2 p = pnext;
+      if (i + 64 < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)(i + 64));   // next step's points in flight
       const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
       const unsigned h = ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);   // iz = 0
       // lanes of this step that use the same slot, and this lane's turn among them
@@ -2103,14 +2105,13 @@ prefilter_kernel(const float *__restrict__ xy, size_t stride, const unsigned lon
       for (int turn = 0; turn < 64; ++turn) {
         if (!__ballot(active && rank >= turn)) break;
         if (active && rank == turn) {
-          int cnt = s_cnt[h];
-          float cx = s_cx[h], cy = s_cy[h];
-          if (cnt && (ix != s_ix[h] || iy != s_iy[h])) {     // another voxel holds the slot: flush it
-            flushed = true; fx = cx / (float)cnt; fy = cy / (float)cnt;
-            cnt = 0; cx = 0.f; cy = 0.f;
+          PfSlot e = slot[h];
+          if (e.cnt && (ix != e.ix || iy != e.iy)) {          // another voxel holds the slot: flush it
+            flushed = true; fx = e.cx / (float)e.cnt; fy = e.cy / (float)e.cnt;
+            e.cnt = 0; e.cx = 0.f; e.cy = 0.f;
           }
-          s_ix[h] = ix; s_iy[h] = iy; s_cnt[h] = cnt + 1;
-          s_cx[h] = cx + p.x; s_cy[h] = cy + p.y;
+          e.ix = ix; e.iy = iy; e.cnt += 1; e.cx += p.x; e.cy += p.y;
+          slot[h] = e;
         }
         __builtin_amdgcn_wave_barrier();
       }
@@ -2119,11 +2120,10 @@ prefilter_kernel(const float *__restrict__ xy, size_t stride, const unsigned lon
       nout += __builtin_popcountll(fb);
     }
     for (int h0 = 0; h0 < kPfSlots; h0 += 64) {              // what is left, in slot order
-      const int h = h0 + lane;
-      const int cnt = s_cnt[h];
-      const unsigned long long fb = __ballot(cnt > 0);
-      if (cnt > 0) tmp[o0 + (unsigned long long)(nout + __builtin_popcountll(fb & lt))] =
-          make_float2(s_cx[h] / (float)cnt, s_cy[h] / (float)cnt);
+      const PfSlot e = slot[h0 + lane];
+      const unsigned long long fb = __ballot(e.cnt > 0);
+      if (e.cnt > 0) tmp[o0 + (unsigned long long)(nout + __builtin_popcountll(fb & lt))] =
+          make_float2(e.cx / (float)e.cnt, e.cy / (float)e.cnt);
       nout += __builtin_popcountll(fb);
     }
     if (lane == 0) counts[b] = (unsigned)nout;
