@@ -2744,7 +2744,7 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
   // only if the read-back disagrees.
   unsigned init_b[4] = {0xffffffffu, 0xffffffffu, 0u, 0u};
   HIP_TRY(ctx, hipMemcpyAsync(m->bounds, init_b, sizeof(init_b), hipMemcpyHostToDevice, st));
-  map_minmax_kernel<<<grid_for(n, 256 * 16, 512), 256, 0, st>>>(xy, stride, n, m->bounds);
+  map_minmax_kernel<<<grid_for(n, 256 * 32, 128), 256, 0, st>>>(xy, stride, n, m->bounds);
   unsigned *hb = ctx->h_bounds;                // pinned
   HIP_TRY(ctx, hipMemcpyAsync(hb, m->bounds, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipEventRecord(ctx->evb, st));

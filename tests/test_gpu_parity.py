@@ -266,6 +266,22 @@ def test_scan_larger_than_the_sort_capacity(gpu, oracle):
     assert_result_parity(gm.align(scan, init), om.align(scan, init))
 
 
+def test_scan_that_misses_the_map(gpu, oracle, c1_world):
+    """A scan far outside the map (empty window, no voxel in reach) and one that only grazes its edge."""
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    scan, truth, init = sf.make(2)
+    for shift in ((500.0, -300.0), (float(np.ptp(m[:, 0])) * 0.98, 0.0)):
+        far = [init[0] + shift[0], init[1] + shift[1], init[2]]
+        r, ref = gm.align(scan, far), om.align(scan, far)
+        assert int(r["status"]) == 0 and int(r["converged"]) == int(ref["converged"])
+        assert int(r["iters"]) == int(ref["iters"])
+        assert (r["T00"], r["T10"], r["T03"], r["T13"]) == (ref["T00"], ref["T10"], ref["T03"], ref["T13"])
+        assert r["fitness"] == pytest.approx(ref["fitness"], rel=1e-12)
+
+
 def test_multi_hypothesis_shared_scan(gpu, oracle, c1_world):
     """configs[4] shape at small size: many seed poses x one scan."""
     capi, ctx = gpu
