@@ -19,7 +19,9 @@ def needs_build():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    deps = [SRC, os.path.join(ROOT, "include", "ndt_mi355x.h"), __file__]
+    csrc = os.path.dirname(SRC)
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h"))]
+    deps += [os.path.join(ROOT, "include", "ndt_mi355x.h"), __file__]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -1,0 +1,98 @@
+// ndt_common.hip.h -- device-side views of the map and small helpers shared by all kernels.
+// Part of libndt_mi355x.so: included by ndt_mi355x.hip inside its anonymous namespace (one translation
+// unit; the order of the includes matters).  Not a standalone header.
+
+// ------------------------------------------------------------------------------------------
+// device-side views
+// ------------------------------------------------------------------------------------------
+
+// Dense voxel grid padded by 2 cells on every side so that the 3x3 probe of any point whose
+// voxel lies within one cell of the map's bounding box needs no bounds checks.
+struct MapView {
+  float inv_leaf, leaf, r2;
+  int radius_inclusive, transform_sse;
+  int min_bx, min_by, div_x, div_y;  // unpadded voxel grid (VoxelGridCovariance min_b_/div_b_)
+  int gw, gh;                        // padded: div + 4
+  const float2 *cent;                // gw*gh float32 centroids; +inf where the voxel is not in
+                                     // the centroid search set (fewer than min_pts points)
+  const double *rec;                 // gw*gh records of 8 doubles (64 B):
+                                     // mean_x, mean_y, icov_xx, icov_xy, icov_yy, 3 pad
+  const unsigned *occ;               // one bit per voxel of the unpadded grid: in the centroid search set
+  const int *pt_start;               // div_x*div_y + 1 bucket offsets of the raw points
+  const float2 *pts;                 // raw points bucketed by voxel, input order kept (a7)
+  double d1, d2;                     // Gaussian constants (a3)
+};
+
+struct OptParams {
+  double step_size, trans_eps, snap_thresh, mt_mu, mt_nu;
+  int max_iter, conv_ge, stale_h_ang, mt_max_iter;
+};
+
+struct Tf32 { float c, s, tx, ty; };
+
+// eleven partial sums of one derivative pass
+struct Acc {
+  double e, g0, g1, g2, hxx, hxy, hxt, hyy, hyt, htt;
+  unsigned pairs;
+};
+constexpr int kAcc = 11;
+
+enum Phase : int { PH_INIT = 0, PH_LS_FIRST = 1, PH_LS_INNER = 2, PH_DONE = 3 };
+
+// Resumable optimiser state of one match.  One lane advances it after every derivative pass;
+// kept free of any per-workgroup assumption so a pass can be produced by any set of waves.
+struct AlignState {
+  int phase, iters, evals, ref_evals, converged, step_iterations, open_interval, interval_converged;
+  Tf32 T;                       // final_transformation_ (float32)
+  double cj, sj, ch, sh;        // angle terms of J_E and of the (yaw,yaw) block of H_E
+  double p[3], dir[3], xt[3];
+  double score, g[3], H[6];     // xx xy xt yy yt tt
+  double phi0, dphi0, a_l, f_l, g_l, a_u, f_u, g_u, a_t;
+  double pairs;
+  double n_points;
+};
+
+// ------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float2 load_pt(const float *xy, size_t stride, size_t i) {
+  return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(xy) + i * stride);
+}
+
+// float32 matrix of the fp64 parameter vector (a4): Translation3f(float(p0), float(p1), 0) *
+// AngleAxisf(float(p2), Z); std::cos/std::sin(float) modelled as correctly rounded.
+__device__ __forceinline__ Tf32 tf_from_p(const double p[3]) {
+  Tf32 t;
+  float yaw = (float)p[2];
+  double sd, cd;
+  sincos((double)yaw, &sd, &cd);
+  t.c = (float)cd;
+  t.s = (float)sd;
+  t.tx = (float)p[0];
+  t.ty = (float)p[1];
+  return t;
+}
+
+// pcl::transformPointCloud on a z = 0 point, float32, no contraction.
+__device__ __forceinline__ void tf_apply(const Tf32 &t, int sse, float x, float y, float &ox,
+                                         float &oy) {
+  float ms = -t.s;
+  float a = t.c * x, b = ms * y, c = t.s * x, d = t.c * y;
+  if (!sse) {
+    float r = a + b; ox = r + t.tx;
+    float q = c + d; oy = q + t.ty;
+  } else {
+    float r = b + t.tx; ox = a + r;
+    float q = d + t.ty; oy = c + q;
+  }
+}
+
+__device__ __forceinline__ bool finite2(float x, float y) {
+  return (fabsf(x) <= FLT_MAX) && (fabsf(y) <= FLT_MAX);
+}
+
+__device__ __forceinline__ void angle_cs(double snap, double yaw, double &c, double &s) {
+  if (fabs(yaw) < snap) { c = 1.0; s = 0.0; }
+  else { sincos(yaw, &s, &c); }
+}

@@ -1,0 +1,341 @@
+// ndt_front.hip.h -- rows f1-f3: source pre-filter, prediction / fusion around the match, neighbour removal.
+// Part of libndt_mi355x.so: included by ndt_mi355x.hip inside its anonymous namespace (one translation
+// unit; the order of the includes matters).  Not a standalone header.
+
+// ------------------------------------------------------------------------------------------
+// f1: source pre-filter = pcl::ApproximateVoxelGrid::filter on a z = 0 cloud
+// (src/PoseEstimator.cpp:6-10).  The filter is a sequential machine: 512
+// direct-mapped slots, a point either joins the voxel its slot holds or flushes that voxel's
+// centroid to the output and takes the slot; what is left is flushed in slot order at the end.
+// One wave per scan replays it 64 points at a time: lanes whose points hash to different slots
+// update them at once, lanes sharing a slot take turns in point order (the float32 sums of a slot
+// are therefore added in cloud order), and the flushes of a step are written in point order.
+// Output = the reference's output, bit for bit and in the same order.
+// ------------------------------------------------------------------------------------------
+constexpr int kPfSlots = 512;
+struct __attribute__((aligned(8))) PfSlot { int ix, iy, cnt; float cx, cy; int pad; };   // 24 B: one b128 + one b64 LDS read
+__global__ void __launch_bounds__(64)
+prefilter_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
+                 float leaf, float2 *__restrict__ tmp /* at the raw offsets */, unsigned *__restrict__ counts) {
+  __shared__ PfSlot slot[kPfSlots];
+  const int lane = threadIdx.x;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const float inv = 1.0f / leaf;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const unsigned long long o0 = offsets[b];
+    const int n = (int)(offsets[b + 1] - o0);
+    for (int h = lane; h < kPfSlots; h += 64) { PfSlot z; z.ix = 0; z.iy = 0; z.cnt = 0; z.cx = 0.f; z.cy = 0.f; z.pad = 0; slot[h] = z; }
+    __builtin_amdgcn_wave_barrier();
+    int nout = 0;
+    float2 pnext = make_float2(0.f, 0.f);
+    if (lane < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)lane);
+    for (int base = 0; base < n; base += 64) {
+      const int i = base + lane;
+      const bool active = i < n;
+      const float2 p = pnext;
+      if (i + 64 < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)(i + 64));   // next step's points in flight
+      const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
+      const unsigned h = ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);   // iz = 0
+      // lanes of this step that use the same slot, and this lane's turn among them
+      unsigned long long peers = __ballot(active);
+#pragma unroll
+      for (int bit = 0; bit < 9; ++bit) {
+        const unsigned long long one = __ballot(active && ((h >> bit) & 1u));
+        peers &= ((h >> bit) & 1u) ? one : ~one;
+      }
+      const int rank = __builtin_popcountll(peers & lt);
+      bool flushed = false;
+      float fx = 0.f, fy = 0.f;
+      for (int turn = 0; turn < 64; ++turn) {
+        if (!__ballot(active && rank >= turn)) break;
+        if (active && rank == turn) {
+          PfSlot e = slot[h];
+          if (e.cnt && (ix != e.ix || iy != e.iy)) {          // another voxel holds the slot: flush it
+            flushed = true; fx = e.cx / (float)e.cnt; fy = e.cy / (float)e.cnt;
+            e.cnt = 0; e.cx = 0.f; e.cy = 0.f;
+          }
+          e.ix = ix; e.iy = iy; e.cnt += 1; e.cx += p.x; e.cy += p.y;
+          slot[h] = e;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+      const unsigned long long fb = __ballot(flushed);
+      if (flushed) tmp[o0 + (unsigned long long)(nout + __builtin_popcountll(fb & lt))] = make_float2(fx, fy);
+      nout += __builtin_popcountll(fb);
+    }
+    for (int h0 = 0; h0 < kPfSlots; h0 += 64) {              // what is left, in slot order
+      const PfSlot e = slot[h0 + lane];
+      const unsigned long long fb = __ballot(e.cnt > 0);
+      if (e.cnt > 0) tmp[o0 + (unsigned long long)(nout + __builtin_popcountll(fb & lt))] =
+          make_float2(e.cx / (float)e.cnt, e.cy / (float)e.cnt);
+      nout += __builtin_popcountll(fb);
+    }
+    if (lane == 0) counts[b] = (unsigned)nout;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// offsets of the filtered scans: exclusive scan of the counts (one workgroup)
+__global__ void __launch_bounds__(1024)
+prefilter_offsets_kernel(const unsigned *__restrict__ counts, int B, unsigned long long *__restrict__ out_offsets) {
+  __shared__ unsigned long long sh[1024];
+  __shared__ unsigned long long carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < B; base += 1024) {
+    const int i = base + threadIdx.x;
+    const unsigned long long v = i < B ? counts[i] : 0ull;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const unsigned long long t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0ull;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < B) out_offsets[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_offsets[B] = carry;
+}
+
+// filtered points from their raw offsets to the packed output
+__global__ void __launch_bounds__(256)
+prefilter_pack_kernel(const float2 *__restrict__ tmp, const unsigned long long *__restrict__ raw_offsets,
+                      const unsigned long long *__restrict__ out_offsets, int B, float2 *__restrict__ out) {
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const unsigned long long r0 = raw_offsets[b], q0 = out_offsets[b];
+    const unsigned long long n = out_offsets[b + 1] - q0;
+    for (unsigned long long j = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; j < n;
+         j += (unsigned long long)gridDim.x * blockDim.x)
+      out[q0 + j] = tmp[r0 + j];
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------
+// f2: the steps either side of the match for a batch -- odometry prediction (Pose2D::calMotion +
+// calPredPose, src/Pose2D.cpp:5-37, chained as in src/ScanMatcher.cpp:27-32) and, after the
+// match, cost / NDT covariance (src/PoseEstimator.cpp:43-64), the accept test
+// (src/ScanMatcher.cpp:50) and the EKF fusion or the odometry covariance alone
+// (src/PoseFuser.cpp:3-61).  One lane per match, fp64, the oracle's expression order.
+// Poses are (tx, ty, th) with th in degrees (include/ndt_slam/Pose2D.h:14).
+// ------------------------------------------------------------------------------------------
+struct FuseParams { double coe_ndt_cov, coe_vel, coe_omega, del_time, score_thre; };
+__device__ __forceinline__ double f2_deg2rad(double x) { return x * M_PI / 180; }
+__device__ __forceinline__ double f2_rad2deg(double x) { return x * 180 / M_PI; }
+__device__ __forceinline__ double f2_add_angle(double a1, double a2) {
+  double sum = a1 + a2;
+  if (sum < -180) sum += 360; else if (sum >= 180) sum -= 360;
+  return sum;
+}
+__device__ __forceinline__ double f2_sub_angle(double a1, double a2) {
+  double dif = a1 - a2;
+  if (dif < -180) dif += 360; else if (dif >= 180) dif -= 360;
+  return dif;
+}
+__device__ __forceinline__ void f2_inv3(const double m[9], double out[9]) {   // Eigen's fixed 3x3 inverse
+  const double c00 = m[4] * m[8] - m[5] * m[7];
+  const double c10 = m[2] * m[7] - m[1] * m[8];
+  const double c20 = m[1] * m[5] - m[2] * m[4];
+  const double det = c00 * m[0] + c10 * m[3] + c20 * m[6];
+  const double id = 1.0 / det;
+  out[0] = c00 * id; out[1] = c10 * id; out[2] = c20 * id;
+  out[3] = (m[5] * m[6] - m[3] * m[8]) * id;
+  out[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+  out[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+  out[6] = (m[3] * m[7] - m[4] * m[6]) * id;
+  out[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+  out[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+}
+__device__ __forceinline__ void f2_mul3(const double a[9], const double b[9], double o[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      double s = a[3 * i] * b[j];
+      s += a[3 * i + 1] * b[3 + j];
+      s += a[3 * i + 2] * b[6 + j];
+      o[3 * i + j] = s;
+    }
+}
+__device__ __forceinline__ void f2_odo_cov(const double motion[3], const double last[3], const double last_cov[9],
+                                           const FuseParams &p, double cov[9]) {
+  const double dt = p.del_time;
+  const double v = sqrt(motion[0] * motion[0] + motion[1] * motion[1]) / dt;
+  const double omega = f2_deg2rad(motion[2] / dt);
+  const double m00 = p.coe_vel * v * v, m11 = p.coe_omega * omega * omega;
+  const double a = f2_deg2rad(last[2]), c = cos(a), s = sin(a);
+  const double F[9] = {1, 0, -v * dt * s, 0, 1, v * dt * c, 0, 0, 1};
+  const double Ft[9] = {1, 0, 0, 0, 1, 0, F[2], F[5], 1};
+  double t[9], flf[9];
+  f2_mul3(F, last_cov, t); f2_mul3(t, Ft, flf);
+  const double a0 = dt * c, a1 = dt * s;
+  const double ama[9] = {a0 * m00 * a0, a0 * m00 * a1, 0, a1 * m00 * a0, a1 * m00 * a1, 0, 0, 0, dt * m11 * dt};
+#pragma unroll
+  for (int i = 0; i < 9; ++i) cov[i] = flf[i] + ama[i];
+}
+
+__global__ void __launch_bounds__(256)
+predict_kernel(const double *__restrict__ odo_cur, const double *__restrict__ odo_prev,
+               const double *__restrict__ last_pose, int B, double *__restrict__ motion_out,
+               double *__restrict__ pred_out, double *__restrict__ init_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const double *cur = odo_cur + 3 * b, *prev = odo_prev + 3 * b, *last = last_pose + 3 * b;
+  const double ap = f2_deg2rad(prev[2]), cp = cos(ap), sp = sin(ap);
+  const double dx = cur[0] - prev[0], dy = cur[1] - prev[1];
+  double motion[3];
+  motion[0] = cp * dx + sp * dy;
+  motion[1] = -sp * dx + cp * dy;
+  motion[2] = f2_sub_angle(cur[2], prev[2]);
+  const double al = f2_deg2rad(last[2]), cl = cos(al), sl = sin(al);
+  double pred[3];
+  pred[0] = cl * motion[0] + -sl * motion[1] + last[0];
+  pred[1] = sl * motion[0] + cl * motion[1] + last[1];
+  pred[2] = f2_add_angle(last[2], motion[2]);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { motion_out[3 * b + i] = motion[i]; pred_out[3 * b + i] = pred[i]; }
+  if (init_out) {                               // the guess ndt_align takes (src/PoseEstimator.cpp:22-24)
+    init_out[3 * b] = pred[0]; init_out[3 * b + 1] = pred[1]; init_out[3 * b + 2] = f2_deg2rad(pred[2]);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+fuse_kernel(const ndt_result *__restrict__ res, const double *__restrict__ pred_pose,
+            const double *__restrict__ odo_motion, const double *__restrict__ last_pose,
+            const double *__restrict__ last_cov, int B, FuseParams p, double *__restrict__ fused_out,
+            double *__restrict__ cov_out, int *__restrict__ successful_out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const ndt_result r = res[b];
+  double pred[3], motion[3], last[3], lc[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { pred[i] = pred_pose[3 * b + i]; motion[i] = odo_motion[3 * b + i]; last[i] = last_pose[3 * b + i]; }
+#pragma unroll
+  for (int i = 0; i < 9; ++i) lc[i] = last_cov[9 * b + i];
+  const double est[3] = {r.pose[0], r.pose[1], f2_rad2deg(r.pose[2])};
+  const double cost = (r.status == NDT_OK && r.converged) ? r.fitness : 10000000.0;
+  const int successful = cost <= p.score_thre;
+  double fused[3], cov[9];
+  if (!successful) {
+    f2_odo_cov(motion, last, lc, p, cov);
+    fused[0] = pred[0]; fused[1] = pred[1]; fused[2] = pred[2];
+  } else {
+    double nh[9], Q[9], ch[9], sum[9], inv[9], K[9], imk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) nh[i] = -r.H[i];
+    f2_inv3(nh, Q);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Q[i] *= p.coe_ndt_cov;
+    f2_odo_cov(motion, last, lc, p, ch);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) sum[i] = Q[i] + ch[i];
+    f2_inv3(sum, inv);
+    f2_mul3(ch, inv, K);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) imk[i] = ((i % 4 == 0) ? 1.0 : 0.0) - K[i];
+    f2_mul3(imk, ch, cov);
+    const double zh[3] = {est[0] - pred[0], est[1] - pred[1], f2_deg2rad(f2_sub_angle(est[2], pred[2]))};
+    const double mu_hat[3] = {pred[0], pred[1], f2_deg2rad(pred[2])};
+    double mu[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      double s = K[3 * i] * zh[0];
+      s += K[3 * i + 1] * zh[1];
+      s += K[3 * i + 2] * zh[2];
+      mu[i] = s + mu_hat[i];
+    }
+    fused[0] = mu[0]; fused[1] = mu[1]; fused[2] = f2_rad2deg(mu[2]);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) fused_out[3 * b + i] = fused[i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) cov_out[9 * b + i] = cov[i];
+  if (successful_out) successful_out[b] = successful;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// f3 (part): PCFilter::remove_neighborPoint (include/ndt_slam/PCFilter.h:29-56) -- keep the points
+// of `base` that have no point of `list` closer than thre_neighbor, in input order.  The
+// reference tests every pair (O(n*m) on the CPU, the largest cost outside NDT when moving
+// objects are removed, src/PointCloudMap.cpp:15-39); here one lane per base point walks the list
+// through LDS tiles.  The distance is PCLUtil::distance_points' float32 expression
+// (include/ndt_slam/PCLUtil.h:21-23) compared with the double threshold, so the kept set is
+// identical; a ballot prefix keeps the order.
+// ------------------------------------------------------------------------------------------
+constexpr int kRnBlock = 256, kRnTile = 1024;
+__device__ __forceinline__ bool rn_near(float2 p, float2 q, double thre) {
+  const float dx = p.x - q.x, dy = p.y - q.y;
+  const float d2 = dx * dx + dy * dy;            // (+ dz*dz with dz = 0 adds nothing)
+  return (double)sqrtf(d2) < thre;
+}
+__global__ void __launch_bounds__(kRnBlock)
+remove_neighbors_flag_kernel(const float *__restrict__ base, size_t bstride, int nb, const float *__restrict__ list,
+                             size_t lstride, int nl, double thre, unsigned char *__restrict__ keep,
+                             int *__restrict__ block_count) {
+  __shared__ float2 tile[kRnTile];
+  __shared__ int wsum[kRnBlock / 64];
+  const int i = blockIdx.x * kRnBlock + threadIdx.x;
+  float2 p = make_float2(0.f, 0.f);
+  if (i < nb) p = load_pt(base, bstride, (size_t)i);
+  bool flag = i < nb;
+  for (int t0 = 0; t0 < nl; t0 += kRnTile) {
+    const int m = min(kRnTile, nl - t0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < m; j += kRnBlock) tile[j] = load_pt(list, lstride, (size_t)(t0 + j));
+    __syncthreads();
+    if (flag) {                                   // (the reference keeps testing; the outcome is the same)
+      bool near = false;
+      for (int j = 0; j < m; ++j) near = near || rn_near(p, tile[j], thre);
+      flag = !near;
+    }
+  }
+  if (i < nb) keep[i] = flag ? 1 : 0;
+  const unsigned long long b = __ballot(flag);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __builtin_popcountll(b);
+  __syncthreads();
+  if (threadIdx.x == 0) { int s = 0; for (int w = 0; w < kRnBlock / 64; ++w) s += wsum[w]; block_count[blockIdx.x] = s; }
+}
+// exclusive scan of the block counts (one workgroup), total to *n_out
+__global__ void __launch_bounds__(1024)
+remove_neighbors_scan_kernel(int *__restrict__ block_count, int nblocks, unsigned long long *__restrict__ n_out) {
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblocks; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblocks ? block_count[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    if (i < nblocks) block_count[i] = carry + sh[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_out = (unsigned long long)carry;
+}
+__global__ void __launch_bounds__(kRnBlock)
+remove_neighbors_pack_kernel(const float *__restrict__ base, size_t bstride, int nb, const unsigned char *__restrict__ keep,
+                             const int *__restrict__ block_off, float2 *__restrict__ out) {
+  __shared__ int wsum[kRnBlock / 64];
+  const int i = blockIdx.x * kRnBlock + threadIdx.x;
+  const bool flag = i < nb && keep[i];
+  const unsigned long long b = __ballot(flag);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) wsum[wv] = __builtin_popcountll(b);
+  __syncthreads();
+  int off = block_off[blockIdx.x];
+  for (int w = 0; w < wv; ++w) off += wsum[w];
+  if (flag) out[off + __builtin_popcountll(b & ((1ull << lane) - 1ull))] = load_pt(base, bstride, (size_t)i);
+}

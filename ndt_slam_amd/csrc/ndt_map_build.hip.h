@@ -1,0 +1,370 @@
+// ndt_map_build.hip.h -- row a2: voxel normal-distributions build.
+// Part of libndt_mi355x.so: included by ndt_mi355x.hip inside its anonymous namespace (one translation
+// unit; the order of the includes matters).  Not a standalone header.
+
+// ------------------------------------------------------------------------------------------
+// a2: voxel normal-distributions build
+// ------------------------------------------------------------------------------------------
+
+// order-preserving float <-> uint for atomicMin/atomicMax
+__device__ __forceinline__ unsigned f2ord(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ inline float ord2f(unsigned u) {
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  float f;
+#if defined(__HIP_DEVICE_COMPILE__)
+  f = __uint_as_float(u);
+#else
+  memcpy(&f, &u, 4);
+#endif
+  return f;
+}
+
+// getMinMax3D: bounds[0..3] = ord(min x), ord(min y), ord(max x), ord(max y)
+__global__ void __launch_bounds__(256)
+map_minmax_kernel(const float *__restrict__ xy, size_t stride, size_t n, unsigned *__restrict__ bounds) {
+  __shared__ float sh[4][4];
+  float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
+  for (size_t i0 = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i0 < n; i0 += 16 * step) {   // 16 loads in flight
+    float2 p[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const size_t i = i0 + u * step; p[u] = load_pt(xy, stride, i < n ? i : i0); }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      if (!finite2(p[u].x, p[u].y)) continue;
+      mnx = fminf(mnx, p[u].x); mxx = fmaxf(mxx, p[u].x);
+      mny = fminf(mny, p[u].y); mxy = fmaxf(mxy, p[u].y);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = fminf(mnx, __shfl_down(mnx, o)); mny = fminf(mny, __shfl_down(mny, o));
+    mxx = fmaxf(mxx, __shfl_down(mxx, o)); mxy = fmaxf(mxy, __shfl_down(mxy, o));
+  }
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w][0] = mnx; sh[w][1] = mny; sh[w][2] = mxx; sh[w][3] = mxy; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) {
+      mnx = fminf(mnx, sh[k][0]); mny = fminf(mny, sh[k][1]);
+      mxx = fmaxf(mxx, sh[k][2]); mxy = fmaxf(mxy, sh[k][3]);
+    }
+    if (mnx <= mxx) {     // one atomic set per workgroup
+      atomicMin(&bounds[0], f2ord(mnx)); atomicMin(&bounds[1], f2ord(mny));
+      atomicMax(&bounds[2], f2ord(mxx)); atomicMax(&bounds[3], f2ord(mxy));
+    }
+  }
+}
+
+struct GridDims { float inv_leaf; int min_bx, min_by, div_x, div_y, gw, gh; };
+
+__device__ __forceinline__ int voxel_of(const GridDims &G, float2 p) {
+  if (!finite2(p.x, p.y)) return -1;
+  const float fx = fminf(fmaxf(floorf(p.x * G.inv_leaf), -1.0e9f), 1.0e9f), fy = fminf(fmaxf(floorf(p.y * G.inv_leaf), -1.0e9f), 1.0e9f);
+  const int ix = (int)fx - G.min_bx, iy = (int)fy - G.min_by;
+  // never true for the grid of this cloud's own bounding box; a build queued ahead of the bounding
+  // box read-back with the previous grid (ndt_map_build_dev) must stay inside its buffers
+  if (ix < 0 || ix >= G.div_x || iy < 0 || iy >= G.div_y) return -1;
+  return iy * G.div_x + ix;
+}
+
+// Consecutive cloud points usually fall in the same voxel (a map is appended scan by scan, wall by
+// wall), so a wave first merges runs of equal voxel keys among its 64 consecutive points and issues
+// one atomic per run instead of one per point.
+__device__ __forceinline__ void wave_runs(int v, int lane, int &head, int &len) {
+  const int prev = __shfl_up(v, 1);
+  const bool is_head = (lane == 0) || (v != prev);
+  const unsigned long long heads = __ballot(is_head);
+  const unsigned long long below = heads & ((2ull << lane) - 1ull);      // heads at or below this lane
+  head = 63 - __builtin_clzll(below);
+  const unsigned long long above = (lane == 63) ? 0ull : (heads >> (lane + 1));
+  len = above ? (lane + 1 + __builtin_ctzll(above)) - lane : 64 - lane;  // valid in head lanes
+}
+
+__global__ void __launch_bounds__(256)
+map_count_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims G, int *__restrict__ count) {
+  const int lane = threadIdx.x & 63;
+  const size_t nround = (n + 63) / 64 * 64;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nround; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = i < n ? voxel_of(G, load_pt(xy, stride, i)) : -2;
+    int head, len;
+    wave_runs(v, lane, head, len);
+    if (head == lane && v >= 0) atomicAdd(&count[v], len);
+  }
+}
+
+// exclusive scan of count[0..ng) into start[0..ng], three small kernels
+constexpr int kScanBlock = 256, kScanPer = 8, kScanTile = kScanBlock * kScanPer;
+constexpr int kBigVoxel = 16;        // voxels with more points are handled by a whole wave (order, statistics)
+
+__global__ void __launch_bounds__(kScanBlock)
+scan_tile_sums_kernel(const int *__restrict__ in, size_t n, int *__restrict__ tile_sum) {
+  __shared__ int sh[kScanBlock / 64];
+  size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPer;
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) if (base + k < n) s += in[base + k];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kScanBlock / 64; ++w) t += sh[w]; tile_sum[blockIdx.x] = t; }
+}
+
+__global__ void __launch_bounds__(1024)
+scan_tile_offsets_kernel(int *__restrict__ tile_sum, int ntiles, int *__restrict__ total) {
+  // single workgroup: exclusive scan of the tile sums, in place
+  __shared__ int sh[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < ntiles; base += 1024) {
+    int i = base + threadIdx.x;
+    int v = i < ntiles ? tile_sum[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    int incl = sh[threadIdx.x];
+    if (i < ntiles) tile_sum[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ void __launch_bounds__(kScanBlock)
+scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ tile_off,
+                  int *__restrict__ out /* n + 1 */, const int *__restrict__ total,
+                  int *__restrict__ big /* voxels with more than kBigVoxel points */, int *__restrict__ nbig, int big_cap) {
+  __shared__ int sh[kScanBlock];
+  size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPer;
+  int v[kScanPer]; int s = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < kScanBlock; o <<= 1) {
+    int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += t;
+    __syncthreads();
+  }
+  int run = tile_off[blockIdx.x] + sh[threadIdx.x] - s;
+  unsigned bigmask = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    if (base + k < n) out[base + k] = run;
+    run += v[k];
+    if (v[k] > kBigVoxel) bigmask |= 1u << k;
+  }
+  {                                              // list of the big voxels: one atomic per wave
+    const int mine = __builtin_popcount(bigmask), lane = threadIdx.x & 63;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+    const int wave_total = __shfl(incl, 63);
+    int q0 = 0;
+    if (lane == 63 && wave_total > 0) q0 = atomicAdd(nbig, wave_total);
+    q0 = __shfl(q0, 63) + incl - mine;
+#pragma unroll
+    for (int k = 0; k < kScanPer; ++k)
+      if ((bigmask >> k) & 1u) { if (q0 < big_cap) big[q0] = (int)(base + k); ++q0; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4) out[n + threadIdx.x] = *total;   // out[n], + 3 readable copies
+}
+
+__global__ void __launch_bounds__(256)
+map_scatter_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims G,
+                   const int *__restrict__ start, int *__restrict__ fill, int *__restrict__ perm) {
+  const int lane = threadIdx.x & 63;
+  const size_t nround = (n + 63) / 64 * 64;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nround; i += (size_t)gridDim.x * blockDim.x) {
+    const int v = i < n ? voxel_of(G, load_pt(xy, stride, i)) : -2;
+    int head, len;
+    wave_runs(v, lane, head, len);
+    int base = 0;
+    if (head == lane && v >= 0) base = start[v] + atomicAdd(&fill[v], len);   // one slot range per run
+    base = __shfl(base, head);
+    if (v >= 0) perm[base + (lane - head)] = (int)i;                          // cloud order kept inside a run
+  }
+}
+
+// Restore input order inside every bucket (PCL accumulates a voxel's points in cloud order and
+// its float32 centroid sum depends on that order), rank by counting.  Voxels of up to kBigVoxel
+// points: eight lanes per voxel (one wave per voxel spent its time launching waves, 70 % of the
+// voxels being empty); the others, listed by scan_apply_kernel: one wave per voxel.
+constexpr int kOrderVoxPerBlock = 256 / 8 * 4;     // 32 lane groups, 4 voxels each
+__global__ void __launch_bounds__(256)
+map_order_small_kernel(const int *__restrict__ start, size_t ng, const int *__restrict__ perm,
+                       int *__restrict__ perm_sorted) {
+  const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  for (int r = 0; r < 4; ++r) {
+    const size_t g = (size_t)blockIdx.x * kOrderVoxPerBlock + (size_t)r * 32 + grp;
+    if (g >= ng) return;
+    const int s0 = start[g], n = start[g + 1] - s0;
+    if (n > kBigVoxel) continue;
+    for (int e = sub; e < n; e += 8) {
+      const int mine = perm[s0 + e];
+      int rank = 0;
+      for (int j = 0; j < n; ++j) rank += (perm[s0 + j] < mine) ? 1 : 0;
+      perm_sorted[s0 + rank] = mine;
+    }
+  }
+}
+
+constexpr int kBigWavesPerBlock = 4, kBigBlocks = 1024, kBigStage = 512;   // LDS staging: point numbers per wave
+__global__ void __launch_bounds__(256)
+map_order_big_kernel(const int *__restrict__ start, const int *__restrict__ big, const int *__restrict__ nbig,
+                     int big_cap, const int *__restrict__ perm, int *__restrict__ perm_sorted) {
+  __shared__ int stage[kBigWavesPerBlock][kBigStage];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int count = min(*nbig, big_cap);
+  for (int q = blockIdx.x * kBigWavesPerBlock + wv; q < count; q += gridDim.x * kBigWavesPerBlock) {
+    const int g = big[q];
+    const int s0 = start[g], n = start[g + 1] - s0;
+    const bool staged = n <= kBigStage;
+    if (staged) for (int e = lane; e < n; e += 64) stage[wv][e] = perm[s0 + e];
+    __builtin_amdgcn_wave_barrier();            // one wave: its LDS writes are ordered before its later reads
+    for (int e = lane; e < n; e += 64) {
+      const int mine = staged ? stage[wv][e] : perm[s0 + e];
+      int rank = 0;
+      if (staged) { for (int j = 0; j < n; ++j) rank += (stage[wv][j] < mine) ? 1 : 0; }
+      else        { for (int j = 0; j < n; ++j) rank += (perm[s0 + j] < mine) ? 1 : 0; }
+      perm_sorted[s0 + rank] = mine;
+    }
+  }
+}
+
+struct LeafParams { int min_pts, cov_unbiased, cov_init_identity; double eig_mult; };
+
+// Mean, regularised covariance and its inverse of one z = 0 voxel (second loop of
+// VoxelGridCovariance::applyFilter); closed-form 2x2 eigen-decomposition, the z eigenpair is
+// exactly (czz, e_z).  Returns 1 accepted, 0 rejected (icov = 0), -1 rejected with inf icov.
+__device__ int leaf_finalize(const LeafParams &L, int n, double sx, double sy, double sxx,
+                             double sxy, double syy, double szz, double mean[2], double icov[3]) {
+  const double dn = (double)n;
+  const double mx = sx / dn, my = sy / dn;
+  mean[0] = mx; mean[1] = my;
+  icov[0] = icov[1] = icov[2] = 0.0;
+  double cxx, cxy, cyy, czz;
+  if (!L.cov_unbiased) {
+    cxx = (sxx - 2.0 * (sx * mx)) / dn + mx * mx;
+    cxy = (sxy - 2.0 * (sx * my)) / dn + mx * my;
+    cyy = (syy - 2.0 * (sy * my)) / dn + my * my;
+    czz = szz / dn;
+    const double f = (dn - 1.0) / dn;
+    cxx *= f; cxy *= f; cyy *= f; czz *= f;
+  } else {
+    cxx = (sxx - sx * mx) / (dn - 1.0);
+    cxy = (sxy - sx * my) / (dn - 1.0);
+    cyy = (syy - sy * my) / (dn - 1.0);
+    czz = szz / (dn - 1.0);
+  }
+  const double hd = 0.5 * (cxx - cyy), tr = 0.5 * (cxx + cyy);
+  const double rad = sqrt(hd * hd + cxy * cxy);
+  const double l1 = tr - rad, l2 = tr + rad;
+  double vx, vy;
+  if (rad == 0.0) { vx = 1.0; vy = 0.0; }
+  else if (hd >= 0.0) { vx = hd + rad; vy = cxy; }
+  else { vx = cxy; vy = rad - hd; }
+  const double vn = sqrt(vx * vx + vy * vy);
+  if (vn == 0.0) { vx = 1.0; vy = 0.0; } else { vx /= vn; vy /= vn; }
+  // ascending order of {l1, l2, czz}; z first among equals
+  double ev0, ev1, ev2; int k0, k1, k2;   // kind: 0 = l1, 1 = l2, 2 = z
+  if (czz <= l1)      { ev0 = czz; k0 = 2; ev1 = l1; k1 = 0; ev2 = l2; k2 = 1; }
+  else if (czz <= l2) { ev0 = l1; k0 = 0; ev1 = czz; k1 = 2; ev2 = l2; k2 = 1; }
+  else                { ev0 = l1; k0 = 0; ev1 = l2; k1 = 1; ev2 = czz; k2 = 2; }
+  if (ev0 < 0 || ev1 < 0 || ev2 <= 0) return 0;
+  const double thr = L.eig_mult * ev2;
+  bool rebuilt = false;
+  if (ev0 < thr) { ev0 = thr; if (ev1 < thr) ev1 = thr; rebuilt = true; }
+  double n1 = l1, n2 = l2;
+  if (k0 == 0) n1 = ev0; else if (k0 == 1) n2 = ev0;
+  if (k1 == 0) n1 = ev1; else if (k1 == 1) n2 = ev1;
+  if (k2 == 0) n1 = ev2; else if (k2 == 1) n2 = ev2;
+  if (rebuilt) {
+    cxx = n1 * (vy * vy) + n2 * (vx * vx);
+    cxy = -n1 * (vx * vy) + n2 * (vx * vy);
+    cyy = n1 * (vx * vx) + n2 * (vy * vy);
+  }
+  const double det = cxx * cyy - cxy * cxy;
+  icov[0] = cyy / det; icov[1] = -cxy / det; icov[2] = cxx / det;
+  for (int a = 0; a < 3; ++a)
+    if (icov[a] == (double)INFINITY || icov[a] == -(double)INFINITY) return -1;
+  return 1;
+}
+
+// Cell record of one voxel from its sums (shared by the two kernels below).
+__device__ __forceinline__ int write_voxel(const GridDims &G, const LeafParams &L, size_t g, int n, float fx, float fy,
+                                           double sx, double sy, double sxx, double sxy, double syy, double szz,
+                                           float2 *__restrict__ cent, double *__restrict__ rec, int *__restrict__ counters) {
+  if (n < L.min_pts) return 0;
+  const int ix = (int)(g % G.div_x), iy = (int)(g / G.div_x);
+  const size_t pg = (size_t)(iy + 2) * G.gw + (ix + 2);
+  double mean[2], icov[3];
+  const int ok = leaf_finalize(L, n, sx, sy, sxx, sxy, syy, szz, mean, icov);
+  cent[pg] = make_float2(fx / (float)n, fy / (float)n);
+  double *r = rec + pg * 8;
+  r[0] = mean[0]; r[1] = mean[1]; r[2] = icov[0]; r[3] = icov[1]; r[4] = icov[2];
+  return ok > 0 ? n : -n;
+}
+
+// One lane per voxel: sequential sums in cloud order (float32 centroid, fp64 mean / Sxx), bucketed
+// copy of the raw points, cell record.
+__global__ void __launch_bounds__(256)
+map_finalize_kernel(const float *__restrict__ xy, size_t stride, GridDims G, LeafParams L,
+                          const int *__restrict__ start, const int *__restrict__ perm_sorted,
+                          float2 *__restrict__ pts, float2 *__restrict__ cent, double *__restrict__ rec,
+                          int *__restrict__ npts_grid, int *__restrict__ counters /* unused */,
+                          unsigned *__restrict__ occ /* (ng + 31) / 32 words: voxel in the search set */) {
+  const size_t ng = (size_t)G.div_x * G.div_y;
+  size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const bool live = g < ng;
+  int s0 = 0, s1 = 0;
+  if (live) { s0 = start[g]; s1 = start[g + 1]; }
+  const int n = s1 - s0;
+  int flag = 0;
+  if (n > 0) {
+    float fx = 0.f, fy = 0.f;
+    double sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0, szz = 0;
+    if (L.cov_init_identity) { sxx = 1.0; syy = 1.0; szz = 1.0; }
+    for (int s = s0; s < s1; s += 8) {          // eight gathers in flight
+      int ib[8]; float2 pb[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ib[u] = perm_sorted[min(s + u, s1 - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pb[u] = load_pt(xy, stride, (size_t)ib[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (s + u >= s1) break;
+        const float2 p = pb[u];                 // strictly in cloud order: these sums define the voxel
+        pts[s + u] = p;
+        fx += p.x; fy += p.y;
+        const double X = (double)p.x, Y = (double)p.y;
+        sx += X; sy += Y;
+        sxx += X * X; sxy += X * Y; syy += Y * Y;
+      }
+    }
+    flag = write_voxel(G, L, g, n, fx, fy, sx, sy, sxx, sxy, syy, szz, cent, rec, counters);
+  }
+  if (live) npts_grid[g] = flag;
+  const u64 in_set = __ballot(flag != 0);       // the wave's 64 consecutive voxels (blockDim is a multiple of 64)
+  if ((threadIdx.x & 63) == 0 && live) {
+    occ[g >> 5] = (unsigned)in_set;
+    if ((g >> 5) + 1 < (ng + 31) / 32) occ[(g >> 5) + 1] = (unsigned)(in_set >> 32);
+  }
+}
+
+__global__ void fill_f2_kernel(float2 *p, size_t n, float v) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = make_float2(v, v);
+}

@@ -1,0 +1,979 @@
+// ndt_match.hip.h -- the match kernel (rows a3-a9): LDS window, spatial sort, units, work sharing between workgroups.
+// Part of libndt_mi355x.so: included by ndt_mi355x.hip inside its anonymous namespace (one translation
+// unit; the order of the includes matters).  Not a standalone header.
+
+// ------------------------------------------------------------------------------------------
+// the match kernel
+//
+// One workgroup per CU.  Every scan has an OWNER workgroup that holds the optimiser state in LDS
+// and runs the whole match on the device.  A derivative pass (and the fitness pass) is cut into
+// kUnits units of points; each unit is reduced on its own and the pass total is the sum of the
+// unit totals in a fixed order, so the result does not depend on who computed which unit.
+// A workgroup whose own scans are finished becomes a HELPER: it attaches to an unfinished scan,
+// stages that scan's window in its own LDS, registers, and from then on computes its static share
+// of the units of every pass the owner opens.  Matches differ widely in the number of passes they
+// need (mean ~12, max ~40 on the bench workload), so without helpers most of the chip idles
+// behind the slowest scans.
+//
+// Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16): every shared word (epoch word,
+// arrival counter, ready counter, pose block, unit totals) is read and written ONLY with
+// agent-scope relaxed atomics (sc1 loads / write-through stores), payload stores are drained
+// (s_waitcnt vmcnt(0)) before the word that signals them, and the one bulk hand-off (the owner's
+// ordered scan copy, marked-cell bitmap and window geometry) uses plain stores + agent release
+// fence on the owner and an agent acquire fence on the helper.  No workgroup ever waits for a
+// workgroup that is not running: a helper is only counted in after it has registered, at which
+// point it does nothing but poll the scan's epoch word; helpers themselves only poll.
+// Every spin is bounded by a watchdog that raises the abort word.
+// ------------------------------------------------------------------------------------------
+constexpr int kBlock = 1024;
+constexpr int kWaves = kBlock / 64;
+constexpr int kSub = 4;                      // a lane's points are cut into kSub runs -> kSub units per wave
+constexpr int kUnits = kWaves * kSub;        // units per pass
+constexpr int kMaxHelpers = 15;              // helper workgroups per scan, hard limit (64 units: 4 each)
+#ifndef NDT_IDLE_MAX
+#define NDT_IDLE_MAX 800           // idle helper back-off: 4 us doubling up to 8 us (100 MHz ticks)
+#endif
+#ifndef NDT_HELPER_PENALTY
+#define NDT_HELPER_PENALTY 12    // passes a scan must be ahead by before it gets one more helper than another
+#endif
+#ifndef NDT_BASE_HELPERS
+#define NDT_BASE_HELPERS 7
+#endif
+constexpr int kBaseHelpers = NDT_BASE_HELPERS;              // ... while more scans are unfinished than workgroups / 8
+constexpr unsigned kEpochDone = 0xFFFFFFFFu;
+constexpr unsigned long long kWatchTicks = 400000000ull;   // ~4 s of the 100 MHz wall clock
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+
+// Per-scan control block: four 128-byte lines, so that the words touched by different parties
+// (epoch polls / arrivals / attach + ready counts / pose reads) never share a line.
+//
+// The epoch word describes one SEGMENT of a pass -- units [ubeg, uend) split over the owner and the
+// first `h` registered helpers: participant k (0 = owner, k = helper rank + 1) computes the units
+// ubeg + k + j*(h+1).  The assignment is static (no claim atomics: a same-address agent-scope
+// read-modify-write costs ~0.1 us and 128 waves used to queue on it every pass); it is safe because a
+// helper only counts once it has registered in `ready`, after which it does nothing but poll this word.
+struct alignas(128) ScanCtl {
+  u64 ticket;        // line 0: epoch << 32 | kind << 24 | h << 16 | uend << 8 | ubeg.  epoch 0: not open; kEpochDone: finished
+  u64 pad0_[15];
+  u32 arrive;        // line 1: units published by helpers in the open epoch (one add per helper workgroup)
+  u32 pad1_[31];
+  u32 helpers;       // line 2: helper workgroups attached; geometry published by the owner's release
+  int region[6];
+  u32 passes;        //         passes the owner has run so far (helpers go where most were needed)
+  u32 ready;         //         helpers whose window is staged; rank = order of registration
+  u32 phase;         //         1: the scan is in its fitness pass (a helper needs no window)
+  u32 use_sorted;    //         1: passes read the scan from the sorted scratch copy
+  u32 owner_wg;      //         workgroup that owns the scan (its scratch slot when every match uses scan 0)
+  int pad2_[20];
+  u64 pose[6];       // line 3: float32 transform (c|s, tx|ty) and the four fp64 angle terms
+  u64 pad3_[10];
+};
+static_assert(sizeof(ScanCtl) == 512, "ScanCtl is four 128-byte lines");
+
+struct WsHeader { u32 done; u32 abort; u32 next; u32 pad[29]; };   // next: scans handed out beyond the first gridDim.x
+static_assert(sizeof(WsHeader) == 128, "WsHeader");
+
+#define NDT_RLX __ATOMIC_RELAXED
+#define NDT_AGENT __HIP_MEMORY_SCOPE_AGENT
+__device__ __forceinline__ u64 ld64(const u64 *p) { return __hip_atomic_load(p, NDT_RLX, NDT_AGENT); }
+__device__ __forceinline__ u32 ld32(const u32 *p) { return __hip_atomic_load(p, NDT_RLX, NDT_AGENT); }
+__device__ __forceinline__ void st64(u64 *p, u64 v) { __hip_atomic_store(p, v, NDT_RLX, NDT_AGENT); }
+__device__ __forceinline__ void st32(u32 *p, u32 v) { __hip_atomic_store(p, v, NDT_RLX, NDT_AGENT); }
+// reads through a memory-side read-modify-write: never served from a stale L2 line of this XCD
+__device__ __forceinline__ u64 rd64_fresh(u64 *p) { return __hip_atomic_fetch_add(p, 0ull, NDT_RLX, NDT_AGENT); }
+__device__ __forceinline__ u32 rd32_fresh(u32 *p) { return __hip_atomic_fetch_add(p, 0u, NDT_RLX, NDT_AGENT); }
+__device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_down(v, o); v = t < v ? t : v; }
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { int t = __shfl_down(v, o); v = t > v ? t : v; }
+  return v;
+}
+
+// pose block of the pass being computed (LDS copy)
+struct PassPose { Tf32 T; double cj, sj, ch, sh; int kind; };
+
+struct Lds {
+  AlignState S;
+  PassPose PP;
+  Region RG;
+  int sbox[4];
+  int swave[kWaves + 1];
+  int sflag[4];
+  double wpart[kUnits * 12];       // unit totals this workgroup computed in the open pass
+  double wtmp[kWaves * 12];        // helper waves: the unit just computed, before it is published
+  double tot[12];                  // pass totals
+  unsigned long long own_mask;     // units of the open pass computed by this workgroup
+  unsigned long long hpose[8];     // helper: pose block of the open epoch, staged by wave 0
+  unsigned long long hword;        // helper: epoch word seen by wave 0
+  int hrank;                       // helper: order of registration on its scan
+  int jnext, stop;                 // units of the open segment handed out so far; close the segment
+  unsigned diag[2];                // diagnostic: ticks of fill_window's first two phases
+  double etab[64];
+};
+
+__device__ __forceinline__ Window window_of(const Region &R, const uint4 *pool) {
+  Window W;
+  W.R = R;
+  W.slot = reinterpret_cast<const unsigned short *>(pool);
+  W.ent = reinterpret_cast<const CellEntry *>(reinterpret_cast<const char *>(pool) +
+                                              ((R.rw * R.rh * 2 + 15) / 16) * 16);
+  return W;
+}
+
+// Owner: bounding box of the scan's voxel coordinates at the first pose -> window geometry.
+template <bool SSE>
+__device__ __forceinline__ void compute_region(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
+                                               int n, Lds &L) {
+  if (threadIdx.x == 0) { L.sbox[0] = INT_MAX; L.sbox[1] = INT_MAX; L.sbox[2] = INT_MIN; L.sbox[3] = INT_MIN; }
+  __syncthreads();
+  int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    const float2 pt = scan[i];
+    float xt, yt;
+    tf_apply_t<SSE>(T0, pt.x, pt.y, xt, yt);
+    if (!finite2(xt, yt)) continue;
+    const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const int ix = (int)fx - M.min_bx, iy = (int)fy - M.min_by;
+    mnx = ix < mnx ? ix : mnx; mxx = ix > mxx ? ix : mxx;
+    mny = iy < mny ? iy : mny; mxy = iy > mxy ? iy : mxy;
+  }
+  mnx = wave_min_i(mnx); mny = wave_min_i(mny); mxx = wave_max_i(mxx); mxy = wave_max_i(mxy);
+  if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
+    atomicMin(&L.sbox[0], mnx); atomicMin(&L.sbox[1], mny); atomicMax(&L.sbox[2], mxx); atomicMax(&L.sbox[3], mxy);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Region r = {0, 0, 0, 0, 0, 0};
+    if (L.sbox[0] <= L.sbox[2]) {
+      // clip the bbox to the padded map grid, add the slack, then fit the slot-table budget around
+      // the bbox centre
+      long long x0 = (long long)L.sbox[0] - kRegionMargin, x1 = (long long)L.sbox[2] + kRegionMargin;
+      long long y0 = (long long)L.sbox[1] - kRegionMargin, y1 = (long long)L.sbox[3] + kRegionMargin;
+      x0 = x0 < -2 ? -2 : x0; y0 = y0 < -2 ? -2 : y0;
+      x1 = x1 > M.div_x + 1 ? M.div_x + 1 : x1; y1 = y1 > M.div_y + 1 ? M.div_y + 1 : y1;
+      long long w = x1 - x0 + 1, h = y1 - y0 + 1;
+      if (w > 0 && h > 0) {
+        if (w * h > kRegionCells) {
+          long long w2 = w > 128 ? 128 : w;
+          long long h2 = kRegionCells / w2; if (h2 > h) h2 = h;
+          x0 += (w - w2) / 2; y0 += (h - h2) / 2; w = w2; h = h2;
+        }
+        r.x0 = (int)x0; r.y0 = (int)y0; r.rw = (int)w; r.rh = (int)h;
+      }
+    }
+    const int slot_bytes = ((r.rw * r.rh * 2 + 15) / 16) * 16;
+    int cap = (kPoolBytes - slot_bytes) / (int)sizeof(CellEntry) - 2;   // last two = sentinels
+    r.cap = cap > 0xFFF0 ? 0xFFF0 : cap;
+    L.RG = r;
+  }
+  __syncthreads();
+}
+
+// Owner and helpers: fill the slot table and the compact record table of window L.RG from the map
+// and the marked-cell bitmap in L.wmap.  Slots are numbered in row-major order of the window, so
+// the content depends only on the map, the geometry and the bitmap.  Slot values: < cap a resident
+// record; cap = voxel outside the search set (centroid +inf); cap + 1 = occupied voxel without an
+// LDS record (centroid -inf).  Sets L.RG.nspill = occupied voxels left without a record.
+// Cells are walked 1024 at a time with consecutive lanes on consecutive cells (coalesced centroid
+// and record reads); the row-major numbering comes from wave ballots kept in LDS.
+__device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool) {
+  const Region r = L.RG;
+  const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
+  unsigned short *slot = reinterpret_cast<unsigned short *>(pool);
+  CellEntry *ent = reinterpret_cast<CellEntry *>(reinterpret_cast<char *>(pool) + ((r.rw * r.rh * 2 + 15) / 16) * 16);
+  const u64 t_fill0 = wall_clock64();
+  const int ncell = r.rw * r.rh;
+  const int rounds = (ncell + kBlock - 1) / kBlock;          // <= kRegionCells / kBlock = 16
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  u64 *keepw = reinterpret_cast<u64 *>(L.wpart) + 256;        // [rounds][kWaves] ballots (wmap uses the first 2 KiB)
+  u64 *occw = keepw + 256;
+  int *base = reinterpret_cast<int *>(L.wtmp);                // [256] exclusive prefix of the kept counts
+  // which window cells are in the map's search set: one bit each from the map's occupancy words,
+  // all rounds' loads in flight together, then one ballot per round
+  unsigned ow[kRegionCells / kBlock];
+  const int rw1 = max(r.rw, 1), step_y = kBlock / rw1, step_x = kBlock - step_y * rw1;   // one round further on
+  int ly = (int)threadIdx.x / rw1, lx = (int)threadIdx.x - ly * rw1;
+#pragma unroll
+  for (int j = 0; j < kRegionCells / kBlock; ++j) {
+    const int c = j * kBlock + threadIdx.x;
+    ow[j] = 0u;
+    if (j < rounds && c < ncell) {
+      const int mx = r.x0 + lx, my = r.y0 + ly;
+      if (mx >= 0 && mx < M.div_x && my >= 0 && my < M.div_y) {
+        const size_t g = (size_t)my * M.div_x + mx;
+        ow[j] = (M.occ[g >> 5] >> (g & 31)) & 1u;
+      }
+    }
+    lx += step_x; ly += step_y;
+    if (lx >= rw1) { lx -= rw1; ++ly; }
+  }
+#pragma unroll
+  for (int j = 0; j < kRegionCells / kBlock; ++j) {
+    const u64 ob = __ballot(ow[j] != 0u);
+    if (lane == 0) occw[j * kWaves + wave] = ob;           // rounds past the window: zero
+  }
+  // marked cells dilated by two cells in x and y, on whole words: a voxel gets an LDS record when it
+  // is in the search set and within two cells of a cell a scan point fell in.  (Rows are not word
+  // aligned, so a mark in the first or last two columns of the window also reaches the end of the
+  // neighbouring row: a few more records, nothing else.)
+  unsigned *dx = reinterpret_cast<unsigned *>(keepw);       // 512 words, reused for the result
+  constexpr int kWords = kRegionCells / 32;
+  auto word_at = [&](const unsigned *a, int i) { return (i >= 0 && i < kWords) ? a[i] : 0u; };
+  if (threadIdx.x < kWords) {
+    const int i = threadIdx.x;
+    const unsigned w = wmap[i], pv = word_at(wmap, i - 1), nx = word_at(wmap, i + 1);
+    dx[i] = w | (w << 1) | (w << 2) | (w >> 1) | (w >> 2) | (pv >> 31) | (pv >> 30) | (nx << 31) | (nx << 30);
+  }
+  __syncthreads();
+  unsigned kword = 0;
+  if (threadIdx.x < kWords) {
+    const int i = threadIdx.x;
+    kword = dx[i];
+#pragma unroll
+    for (int m = 1; m <= 2; ++m) {
+      const int sft = m * r.rw, q = sft >> 5, b = sft & 31;
+      // bits moved towards higher cell numbers (from the row(s) above) and towards lower ones (below)
+      kword |= (word_at(dx, i - q) << b) | (b ? (word_at(dx, i - q - 1) >> (32 - b)) : 0u);
+      kword |= (word_at(dx, i + q) >> b) | (b ? (word_at(dx, i + q + 1) << (32 - b)) : 0u);
+    }
+    kword &= reinterpret_cast<const unsigned *>(occw)[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < kWords) dx[threadIdx.x] = kword;        // = keepw, two words per ballot word
+  __syncthreads();
+  if (threadIdx.x == 0) L.diag[0] = (unsigned)(wall_clock64() - t_fill0);
+  // exclusive prefix of the kept counts over the rounds * kWaves ballot words (cell order)
+  const int nword = rounds * kWaves;                           // <= 256
+  if (threadIdx.x < 256) {
+    const int mine = (int)threadIdx.x < nword ? __builtin_popcountll(keepw[threadIdx.x]) : 0;
+    const int skip = (int)threadIdx.x < nword ? __builtin_popcountll(occw[threadIdx.x] & ~keepw[threadIdx.x]) : 0;
+    int incl = mine, sk = skip;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o); if (lane >= o) incl += t;
+      sk += __shfl_xor(sk, o);
+    }
+    base[threadIdx.x] = incl - mine;
+    if (lane == 63) { L.swave[wave] = incl; L.sbox[wave] = sk; }
+  }
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    int add = 0;
+    for (int w = 0; w < wave; ++w) add += L.swave[w];
+    base[threadIdx.x] += add;
+  }
+  if (threadIdx.x == 0) {
+    const int kept = L.swave[0] + L.swave[1] + L.swave[2] + L.swave[3];
+    const int skipped = L.sbox[0] + L.sbox[1] + L.sbox[2] + L.sbox[3];
+    CellEntry z; z.cent = make_float2(INFINITY, INFINITY); z.mx = z.my = z.i00 = z.i01 = z.i11 = 0.0;
+    ent[r.cap] = z;                             // voxels outside the search set
+    z.cent = make_float2(-INFINITY, -INFINITY);
+    ent[r.cap + 1] = z;                         // occupied voxels without an LDS record
+    L.RG.nspill = skipped + (kept > r.cap ? kept - r.cap : 0);
+    L.diag[1] = (unsigned)(wall_clock64() - t_fill0);
+  }
+  __syncthreads();
+  for (int j0 = 0; j0 < rounds; j0 += 4) {                   // four rounds' record loads in flight together
+    int nx[4]; float2 cc[4]; double2 ra[4], rb[4]; double rc[4]; unsigned sl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u, c = j * kBlock + threadIdx.x;
+      nx[u] = -1; sl[u] = (unsigned)r.cap;
+      if (j < rounds && c < ncell) {
+        const u64 kb = keepw[j * kWaves + wave], ob = occw[j * kWaves + wave];
+        if ((ob >> lane) & 1ull) {
+          sl[u] = (unsigned)r.cap + 1u;
+          if ((kb >> lane) & 1ull) {
+            const int next = base[j * kWaves + wave] + __builtin_popcountll(kb & ((1ull << lane) - 1ull));
+            if (next < r.cap) {
+              const int ly = c / r.rw, lx = c - ly * r.rw;
+              const size_t pg = (size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2);
+              const double *rec = M.rec + pg * 8;
+              cc[u] = M.cent[pg];
+              ra[u] = *reinterpret_cast<const double2 *>(rec); rb[u] = *reinterpret_cast<const double2 *>(rec + 2); rc[u] = rec[4];
+              nx[u] = next; sl[u] = (unsigned)next;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u, c = j * kBlock + threadIdx.x;
+      if (nx[u] >= 0) {
+        CellEntry E; E.cent = cc[u]; E.mx = ra[u].x; E.my = ra[u].y; E.i00 = rb[u].x; E.i01 = rb[u].y; E.i11 = rc[u];
+        ent[nx[u]] = E;
+      }
+      if (j < rounds && c < ncell) slot[c] = (unsigned short)sl[u];
+    }
+  }
+  __syncthreads();
+}
+
+// Owner: spatial order of the scan.  The points are sorted by the window cell they fall in at the
+// first pose (row-major cell order, input order kept inside a cell) and written to the scratch copy
+// every pass reads.  The 64 lanes of a wave then always work on neighbouring points -- a rigid
+// transform keeps neighbours together, so this holds at every later pose too -- which means: equal
+// in-radius voxel counts (the pair loop runs max-over-lanes times), LDS probes that hit the same few
+// slots and records (broadcast instead of bank conflicts), and in the fitness pass bucket loads that
+// share cache lines.  The cell histogram also yields the marked-cell bitmap (L.wmap) that
+// fill_window and the helpers use.  Uses the LDS pool as scratch (before the window is staged).
+// Returns false (bitmap still produced, scratch copy not written) when the scan is too large for it.
+constexpr int kSortMax = 20000;             // LDS room for one word per point; point numbers < 2^15
+template <bool SSE>
+__device__ __forceinline__ bool sort_points(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
+                                            int n, Lds &L, uint4 *pool, float2 *__restrict__ sp) {
+  const Region r = L.RG;
+  const int ncell = r.rw * r.rh;
+  unsigned *wmap = reinterpret_cast<unsigned *>(L.wpart);
+  unsigned *hist = reinterpret_cast<unsigned *>(pool);                 // ncell + 1 counters (last: outside the window)
+  unsigned *idx = hist + ((ncell + 1 + 3) & ~3);
+  for (int i = threadIdx.x; i <= ncell; i += kBlock) hist[i] = 0u;
+  for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) wmap[i] = 0u;
+  __syncthreads();
+  auto key_of = [&](float2 pt) {
+    float xt, yt;
+    tf_apply_t<SSE>(T0, pt.x, pt.y, xt, yt);
+    if (!finite2(xt, yt)) return ncell;
+    const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const int lx = (int)fx - M.min_bx - r.x0, ly = (int)fy - M.min_by - r.y0;
+    if (lx < 0 || lx >= r.rw || ly < 0 || ly >= r.rh) return ncell;
+    return ly * r.rw + lx;
+  };
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * kBlock) {      // four loads in flight
+    float2 pt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pt[u] = scan[min(i0 + u * kBlock, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (i0 + u * kBlock < n) atomicAdd(&hist[key_of(pt[u])], 1u);
+  }
+  __syncthreads();
+  // marked-cell bitmap
+  for (int w = threadIdx.x; w < (ncell + 31) / 32; w += kBlock) {
+    unsigned bits = 0;
+    const int c0 = w * 32, c1 = min(c0 + 32, ncell);
+    for (int c = c0; c < c1; ++c) bits |= (hist[c] != 0u ? 1u : 0u) << (c - c0);
+    wmap[w] = bits;
+  }
+  const bool do_sort = sp != nullptr && n <= kSortMax;
+  if (!do_sort) { __syncthreads(); return false; }
+  // exclusive scan of the ncell + 1 counters
+  const int per = (ncell + 1 + kBlock - 1) / kBlock;
+  const int c0 = min((int)threadIdx.x * per, ncell + 1), c1 = min(c0 + per, ncell + 1);
+  unsigned mine = 0;
+  for (int c = c0; c < c1; ++c) mine += hist[c];
+  unsigned incl = mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if ((int)(threadIdx.x & 63) >= o) incl += t; }
+  if ((threadIdx.x & 63) == 63) L.swave[threadIdx.x >> 6] = (int)incl;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int w = 0; w < kWaves; ++w) { const int t = L.swave[w]; L.swave[w] = run; run += t; }
+  }
+  __syncthreads();
+  {
+    unsigned run = (unsigned)L.swave[threadIdx.x >> 6] + incl - mine;
+    for (int c = c0; c < c1; ++c) { const unsigned t = hist[c]; hist[c] = run; run += t; }
+  }
+  __syncthreads();
+  // scatter (cell, point number) packed in one word; afterwards hist[c] = end of cell c
+  for (int i0 = threadIdx.x; i0 < n; i0 += 4 * kBlock) {
+    float2 pt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) pt[u] = scan[min(i0 + u * kBlock, n - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (i0 + u * kBlock >= n) break;
+      const int key = key_of(pt[u]);
+      idx[atomicAdd(&hist[key], 1u)] = ((unsigned)key << 15) | (unsigned)(i0 + u * kBlock);
+    }
+  }
+  __syncthreads();
+  // input order inside a cell (the atomics above arrive in any order): every entry finds its rank among
+  // the entries of its cell -- neighbouring lanes read the same short segment -- and its point goes
+  // straight to that place of the scratch copy
+  for (int p0 = threadIdx.x; p0 < n; p0 += 4 * kBlock) {
+    int dstpos[4]; float2 pt[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int pp = p0 + u * kBlock;
+      dstpos[u] = -1;
+      if (pp < n) {
+        const unsigned v = idx[pp];
+        const int key = (int)(v >> 15);
+        const int s0 = key ? (int)hist[key - 1] : 0, s1 = (int)hist[key];
+        int rank = 0;
+        for (int a = s0; a < s1; ++a) rank += idx[a] < v ? 1 : 0;
+        dstpos[u] = s0 + rank;
+        pt[u] = scan[v & 0x7FFFu];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (dstpos[u] >= 0) sp[dstpos[u]] = pt[u];
+  }
+  __syncthreads();
+  return true;
+}
+
+// Sum of 12 per-lane values over the 64 lanes of a wave in a fixed order, 86 instructions instead
+// of 12 x 18: a butterfly in which every exchange also halves the number of values a lane carries
+// (12 -> 6 -> 3 -> 2 -> 1), so only 24 cross-lane moves are needed.  The total of value j ends in
+// the lanes whose bits select j; those lanes store it to dst[j] (LDS).
+__device__ __forceinline__ void wave_reduce12(const double (&a)[12], int lane, double *__restrict__ dst) {
+  const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+  double k[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {                       // keep values 0..5 (b5 = 0) or 6..11 (b5 = 1)
+    const double keep = b5 ? a[i + 6] : a[i], send = b5 ? a[i] : a[i + 6];
+    k[i] = keep + __shfl_xor(send, 32);
+  }
+  double m[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {                       // keep 0..2 or 3..5 of those
+    const double keep = b4 ? k[i + 3] : k[i], send = b4 ? k[i] : k[i + 3];
+    m[i] = keep + __shfl_xor(send, 16);
+  }
+  const double p0 = (b3 ? m[1] : m[0]) + __shfl_xor(b3 ? m[0] : m[1], 8);   // value 0 or 1 of the triple
+  const double p1 = m[2] + __shfl_xor(m[2], 8);                            // value 2
+  double r = (b2 ? p1 : p0) + __shfl_xor(b2 ? p0 : p1, 4);
+  r += __shfl_xor(r, 2);
+  r += __shfl_xor(r, 1);
+  const int idx = (b5 ? 6 : 0) + (b4 ? 3 : 0) + (b2 ? 2 : (b3 ? 1 : 0));
+  if ((lane & 3) == 0 && !(b2 && b3)) dst[idx] = r;
+}
+
+// Units of a pass: unit u = (virtual wave w = u % kWaves, run q = u / kWaves) is the lane set
+// {w*64 .. w*64+63} walking the q-th run of its points i = w*64 + lane + k*kBlock,
+// k in [q*run, (q+1)*run), of the (ordered) scan.  Any physical wave of any workgroup can compute
+// a unit; its sums are reduced over the 64 lanes in a fixed order, and a pass total is the sum of
+// the kUnits unit totals in unit order -- the same arithmetic whether the owner computed all units
+// itself or helpers computed some.
+// This routine computes the consecutive runs [q0, q1) of virtual wave w in ONE walk over k (the
+// point prefetch keeps running across run boundaries) and leaves the 12 sums of run q at
+// dst[(q - q0) * dst_stride .. +12) (LDS).
+// wave-uniform values read from LDS land in VGPRs; these move them to SGPRs (the pass loop is short of VGPRs)
+__device__ __forceinline__ float uniform_f(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ double uniform_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)b), hi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+  return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+
+template <bool SSE, bool INCL>
+__device__ __forceinline__ void unit_sums(const MapView &M, const Window &W, const double *__restrict__ etab,
+                                          const PassPose &pp_in, const float2 *__restrict__ pts, int n, int w,
+                                          int q0, int q1, double *__restrict__ dst, int dst_stride) {
+  PassPose pp;
+  pp.T.c = uniform_f(pp_in.T.c); pp.T.s = uniform_f(pp_in.T.s); pp.T.tx = uniform_f(pp_in.T.tx); pp.T.ty = uniform_f(pp_in.T.ty);
+  pp.cj = uniform_d(pp_in.cj); pp.sj = uniform_d(pp_in.sj); pp.ch = uniform_d(pp_in.ch); pp.sh = uniform_d(pp_in.sh);
+  pp.kind = __builtin_amdgcn_readfirstlane(pp_in.kind);
+  const int lane = threadIdx.x & 63, last = n - 1;
+  const int per_lane = (n + kBlock - 1) / kBlock;          // points of the longest lane
+  const int run = (per_lane + kSub - 1) / kSub;
+  const int kbeg = min(per_lane, q0 * run), kend = min(per_lane, q1 * run);
+  const int base = w * 64 + lane;
+  if (pp.kind == 0) {
+    Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+    float2 p0 = pts[min(base + kbeg * kBlock, last)], p1 = pts[min(base + (kbeg + 1) * kBlock, last)];
+    int q = q0, kb = min(per_lane, (q0 + 1) * run);        // end of the current run
+#pragma nounroll
+    for (int k = kbeg; k < kend; ++k) {
+      const float2 p2 = pts[min(base + (k + 2) * kBlock, last)];
+      if (base + k * kBlock >= n) p0.x = NAN;              // past the end: contributes nothing
+      eval_point<SSE, INCL>(M, W, etab, pp.T, p0.x, p0.y, pp.cj, pp.sj, pp.ch, pp.sh, A);
+      p0 = p1; p1 = p2;
+      if (k + 1 == kb) {                                   // run q complete (uniform across the wave)
+        const double a[12] = {A.e, A.g0, A.g1, A.g2, A.hxx, A.hxy, A.hxt, A.hyy, A.hyt, A.htt, (double)A.pairs, 0.0};
+        wave_reduce12(a, lane, dst + (q - q0) * dst_stride);
+        A = Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+        ++q; kb = min(per_lane, (q + 1) * run);
+      }
+    }
+    for (; q < q1; ++q) {                                  // empty runs (short scans)
+      if (lane < 12) dst[(q - q0) * dst_stride + lane] = 0.0;
+    }
+  } else {
+    for (int q = q0; q < q1; ++q) {
+      const int k0 = min(per_lane, q * run), k1 = min(per_lane, (q + 1) * run);
+      double fsum = 0.0, fcnt = 0.0;
+      for (int k = k0; k < k1; ++k) {
+        const int i = base + k * kBlock;
+        if (i >= n) break;
+        const float2 pt = pts[i];
+        float qx, qy;
+        tf_apply_t<SSE>(pp.T, pt.x, pt.y, qx, qy);
+        if (!finite2(qx, qy)) continue;
+        const float best = nearest_sq(M, qx, qy);
+        if (best < INFINITY) { fsum += (double)best; fcnt += 1.0; }
+      }
+      fsum = wave_sum(fsum); fcnt = wave_sum(fcnt);
+      if (lane == 0) { dst[(q - q0) * dst_stride] = fsum; dst[(q - q0) * dst_stride + 1] = fcnt; }
+    }
+  }
+}
+
+// Bound on every spin: looked at once per 64 polls (the abort word is one line shared by the chip).
+__device__ __forceinline__ bool watchdog(WsHeader *hdr, u64 t_start, unsigned &polls) {
+  if ((++polls & 63u) != 0u) return false;
+  if (ld32(&hdr->abort)) return true;
+  if (wall_clock64() - t_start > kWatchTicks) { st32(&hdr->abort, 1u); return true; }
+  return false;
+}
+
+__device__ __forceinline__ u64 wave_bcast64(u64 v) {   // lane 0's value to the whole wave
+  const u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+  return ((u64)hi << 32) | lo;
+}
+
+template <bool SSE, bool INCL>
+__global__ void __launch_bounds__(kBlock)
+ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
+                 const unsigned long long *__restrict__ offsets, int B, int shared_scan,
+                 const double *__restrict__ inits, ndt_result *__restrict__ results,
+                 double *__restrict__ trace, int trace_cap, int *__restrict__ trace_rows,
+                 float2 *__restrict__ sorted /* scratch, same offsets as scans; may be null */,
+                 unsigned char *__restrict__ ws /* WsHeader, ScanCtl[B], unit totals[B][kUnits][12], marked-cell bitmaps[B][kRegionCells/32] */,
+                 int allow_helpers /* 0: none; else max helper workgroups per scan */,
+                 unsigned long long *__restrict__ prof /* diagnostic: 8 words per scan */) {
+  __shared__ Lds L;
+  __shared__ uint4 pool[kPoolBytes / 16];
+  WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
+  ScanCtl *ctl = reinterpret_cast<ScanCtl *>(ws + sizeof(WsHeader));
+  u64 *utot = reinterpret_cast<u64 *>(ws + sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl));
+  unsigned *wantmap = reinterpret_cast<unsigned *>(ws + sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl) +
+                                                  (size_t)B * kUnits * 12 * sizeof(double));
+  const u64 t_start = wall_clock64();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x < 64) L.etab[threadIdx.x] = c_exp2_tab[threadIdx.x];
+  bool aborted = false;
+
+  // =========================== owner of scans blockIdx.x, + gridDim.x, ... ===========================
+  // scans are taken from a queue: the first gridDim.x by workgroup number, the rest in the order
+  // workgroups become free (results do not depend on who owns which scan)
+  for (int b = blockIdx.x; b < B && !aborted;) {
+    const u64 o0 = shared_scan ? offsets[0] : offsets[b];
+    const u64 o1 = shared_scan ? offsets[1] : offsets[b + 1];
+    const int n = (int)(o1 - o0);
+    const float2 *scan = reinterpret_cast<const float2 *>(scans) + o0;
+    double *tr = trace ? trace + (size_t)b * trace_cap * 8 : nullptr;
+    ScanCtl *C = ctl + b;
+    u64 *mytot = utot + (size_t)b * kUnits * 12;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      init_state(L.S, P, inits + 3 * (size_t)b, (double)n);
+      if (trace_rows) trace_rows[b] = 0;
+      if (n <= 0) { L.S.phase = PH_DONE; L.S.converged = 0; }
+    }
+    __syncthreads();
+    const float2 *pts = scan;
+    if (n > 0) {
+      const u64 q0 = wall_clock64();
+      compute_region<SSE>(M, L.S.T, scan, n, L);
+      const u64 q1 = wall_clock64();
+      // scratch copy: at the scan's own offsets, or (every match uses scan 0) one slot per workgroup
+      float2 *sp = sorted ? (shared_scan ? sorted + (size_t)blockIdx.x * (size_t)n : sorted + o0) : nullptr;
+      if (sort_points<SSE>(M, L.S.T, scan, n, L, pool, sp)) pts = sp;
+      const u64 q2 = wall_clock64();
+      if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
+        const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
+        unsigned *gw = wantmap + (size_t)b * (kRegionCells / 32);
+        for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) gw[i] = wmap[i];
+      }
+      if (allow_helpers) {
+        // publish geometry + marked cells + ordered copy before staging the own window, so that idle
+        // workgroups stage theirs meanwhile: plain stores, drained by every wave, then one agent release
+        if (threadIdx.x == 0) {
+          const Region r = L.RG;
+          C->region[0] = r.x0; C->region[1] = r.y0; C->region[2] = r.rw; C->region[3] = r.rh;
+          C->region[4] = r.cap; C->region[5] = r.nspill;
+          C->use_sorted = (pts != scan) ? 1u : 0u;
+          C->owner_wg = blockIdx.x;
+        }
+        drain_vmem();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          drain_vmem();
+          st64(&C->ticket, (u64)1 << 32);                     // epoch 1: open for joining, nothing to compute (h = 0)
+        }
+      }
+      fill_window(M, L, pool);
+      const u64 q3 = wall_clock64();
+      if (prof && threadIdx.x == 0) {
+        const u64 q4 = wall_clock64();
+        prof[8 * (size_t)B + 8 * (size_t)b + 6] = ((q1 - q0) << 32) | ((q2 - q1) & 0xFFFFFFFFull);
+        prof[8 * (size_t)B + 8 * (size_t)b + 7] = ((q3 - q2) << 32) | ((u64)(L.diag[0] & 0xFFFFu) << 16) | (u64)(L.diag[1] & 0xFFFFu);
+      }
+    }
+    const Window W = window_of(L.RG, pool);
+    if (threadIdx.x == 0) L.sflag[1] = 0;            // registered helpers (refreshed during every advance)
+    unsigned epoch = 1;
+    u64 t_eval = 0, t_adv = 0, tt0 = 0, tt1 = 0, t_wait = 0, t_first_shared = 0, t_fit = 0;
+    u64 ts1 = 0, ts2 = 0, ts3 = 0, a_pro = 0, a_own = 0, a_wait = 0, a_comb = 0, a_adv = 0, a_n = 0;   // shared derivative passes (diagnostic)
+    const u64 t_scan0 = wall_clock64() - t_start;
+    unsigned n_shared = 0, n_helped = 0;
+    bool fitness_done = false;
+    // ---- passes: derivative passes until the optimiser stops, then one fitness pass ----
+    while (n > 0 && !fitness_done) {
+      if (prof) tt0 = wall_clock64();
+      const bool fit_pass = (L.S.phase == PH_DONE);
+      // A pass is run as one or more SEGMENTS of consecutive units.  A derivative pass is one segment:
+      // solo (one walk per wave) or split over the registered helpers.  The fitness pass runs once, can
+      // be long (a poor match walks many rings per point) and usually starts when no helper is free:
+      // solo, its units are handed to the waves one at a time from an LDS counter and the segment is
+      // closed as soon as a helper has registered, so that the rest of the pass is shared.
+      int pass_h = 0, ubeg = 0;
+      bool pose_out = false;                       // thread 0: pose block of this pass is in the control block
+      for (int seg = 0; seg <= kUnits && ubeg < kUnits; ++seg) {
+        if (threadIdx.x == 0) {
+          if (seg == 0) {
+            L.PP.T = L.S.T; L.PP.cj = L.S.cj; L.PP.sj = L.S.sj; L.PP.ch = L.S.ch; L.PP.sh = L.S.sh;
+            L.PP.kind = fit_pass ? 1 : 0;
+            if (allow_helpers) { st32(&C->passes, (u32)L.S.evals); if (fit_pass) st32(&C->phase, 1u); }
+          } else if (allow_helpers) {
+            L.sflag[1] = (int)ld32(&C->ready);
+          }
+          const int h = allow_helpers ? min(L.sflag[1], kMaxHelpers) : 0;
+          L.sflag[0] = h;
+          L.jnext = 0; L.stop = 0;
+          if (h > 0) {                          // open an epoch: pose block, then the epoch word
+            const PassPose pp = L.PP;
+            if (!pose_out) {
+              pose_out = true;
+              st64(&C->pose[0], ((u64)__float_as_uint(pp.T.s) << 32) | (u64)__float_as_uint(pp.T.c));
+              st64(&C->pose[1], ((u64)__float_as_uint(pp.T.ty) << 32) | (u64)__float_as_uint(pp.T.tx));
+              st64(&C->pose[2], (u64)__double_as_longlong(pp.cj)); st64(&C->pose[3], (u64)__double_as_longlong(pp.sj));
+              st64(&C->pose[4], (u64)__double_as_longlong(pp.ch)); st64(&C->pose[5], (u64)__double_as_longlong(pp.sh));
+            }
+            st32(&C->arrive, 0u);
+            drain_vmem();
+            st64(&C->ticket, ((u64)(epoch + 1) << 32) | ((u64)pp.kind << 24) | ((u64)h << 16) | ((u64)kUnits << 8) | (u64)ubeg);
+          }
+        }
+        __syncthreads();
+        if (prof) ts1 = wall_clock64();
+        const int nhelp = L.sflag[0];
+        const PassPose pp = L.PP;
+        int uend = kUnits;
+        if (nhelp <= 0 && !fit_pass) {
+          // solo derivative pass: wave w computes its own units (w, 0..kSub-1) in one walk
+          unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, wave, 0, kSub, L.wpart + wave * 12, kWaves * 12);
+        } else {
+          // this workgroup's units ubeg + j*(nhelp+1), j = 0, 1, ... handed to its waves from an LDS counter
+          const bool watch = fit_pass && nhelp == 0 && allow_helpers;
+          for (int it = 0; it <= kUnits; ++it) {             // counted (tools/repro/ticket2.hip)
+            if (watch && L.stop) break;
+            int j = 0;
+            if (lane == 0) j = atomicAdd(&L.jnext, 1);
+            j = __builtin_amdgcn_readfirstlane(j);
+            const int u = ubeg + j * (nhelp + 1);
+            if (u >= kUnits) break;
+            unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, u % kWaves, u / kWaves, u / kWaves + 1, L.wpart + u * 12, 0);
+            if (watch && wave == kWaves - 1 && lane == 0) {
+              // one wave looks for a registered helper between its units.  (Raising the scan's priority
+              // when this pass runs long was tried: it draws helpers away from the scans that still have
+              // tens of passes to go and cost 5 % of the batch rate.)
+              if (ld32(&C->ready) > 0u) L.stop = 1;
+            }
+          }
+          if (watch) {                                       // units [ubeg, ubeg + claimed) are done
+            __syncthreads();
+            uend = min(kUnits, ubeg + L.jnext);
+          }
+        }
+        if (nhelp > 0) {
+          ++epoch;
+          pass_h = nhelp;
+          __syncthreads();
+          if (prof) ts2 = wall_clock64();
+          // wait for the helpers' units (every counted helper is polling the epoch word or computing)
+          if (threadIdx.x == 0) {
+            const int total = kUnits - ubeg;
+            const int mine = (total + nhelp) / (nhelp + 1);
+            const u32 need = (u32)(total - mine);
+            int bad = 0; unsigned polls = 0;
+            const u64 w0 = wall_clock64();
+            while (ld32(&C->arrive) < need) {
+              if (watchdog(hdr, t_start, polls)) { bad = 1; break; }
+              __builtin_amdgcn_s_sleep(2);
+            }
+            t_wait += wall_clock64() - w0;
+            if (n_shared == 0) t_first_shared = w0 - t_start;
+            n_shared += 1; n_helped += need;
+            L.sflag[2] = bad;
+          }
+          __syncthreads();
+          if (prof) ts3 = wall_clock64();
+          if (L.sflag[2]) { aborted = true; break; }
+          // helpers' totals of this segment: one load per lane, in flight together
+          if (threadIdx.x < (kUnits - ubeg) * 12) {
+            const int u = ubeg + threadIdx.x / 12;
+            if ((u - ubeg) % (nhelp + 1) != 0)
+              L.wpart[ubeg * 12 + threadIdx.x] = __longlong_as_double((long long)ld64(&mytot[ubeg * 12 + threadIdx.x]));
+          }
+        }
+        __syncthreads();
+        ubeg = uend;
+      }
+      if (aborted) break;
+      // pass total: the units in four groups of 16, each summed in unit order by one lane per value,
+      // then the four partial sums in order; wave 0 goes straight on to the optimiser step
+      static_assert(kUnits == 64, "four groups of 16 units");
+      if (threadIdx.x < 64) {
+        const int j = lane % 12, grp = lane / 12;             // lanes 48..63: nothing to add
+        double part = 0.0;
+        if (lane < 48) for (int v = 16 * grp; v < 16 * grp + 16; ++v) part += L.wpart[v * 12 + j];
+        const double p1 = __shfl(part, j + 12), p2 = __shfl(part, j + 24), p3 = __shfl(part, j + 36);
+        if (lane < 12) L.tot[lane] = ((part + p1) + p2) + p3;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (prof) { tt1 = wall_clock64(); }
+        if (!fit_pass && lane == 0) advance(L.S, P, M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
+      }
+      // meanwhile another wave fetches the number of registered helpers for the next pass
+      if (!fit_pass && threadIdx.x == 64 && allow_helpers) L.sflag[1] = (int)rd32_fresh(&C->ready);
+      if (fit_pass) fitness_done = true;
+      __syncthreads();
+      if (prof) {
+        const u64 te = wall_clock64();
+        if (threadIdx.x >= 64) tt1 = te;          // (only wave 0 stamps the end of the summation)
+        t_eval += tt1 - tt0; if (fit_pass) t_fit = tt1 - tt0;
+        t_adv += te - tt1;
+        if (pass_h > 0 && !fit_pass) { a_pro += ts1 - tt0; a_own += ts2 - ts1; a_wait += ts3 - ts2; a_comb += tt1 - ts3; a_adv += te - tt1; a_n += 1; }
+      }
+    }
+    // ---- result record; close the scan ----
+    if (threadIdx.x == 0) {
+      const AlignState &S = L.S;
+      const Tf32 T = S.T;
+      ndt_result R_;
+      R_.pose[0] = (double)T.tx; R_.pose[1] = (double)T.ty; R_.pose[2] = yaw_from_T(T.c, T.s);
+      R_.T00 = T.c; R_.T10 = T.s; R_.T03 = T.tx; R_.T13 = T.ty;
+      R_.fitness = (fitness_done && L.tot[1] > 0) ? L.tot[0] / L.tot[1] : DBL_MAX;
+      R_.score = S.score;
+      R_.trans_prob = n > 0 ? S.score / (double)n : 0.0;
+      R_.H[0] = S.H[0]; R_.H[1] = S.H[1]; R_.H[2] = S.H[2];
+      R_.H[3] = S.H[1]; R_.H[4] = S.H[3]; R_.H[5] = S.H[4];
+      R_.H[6] = S.H[2]; R_.H[7] = S.H[4]; R_.H[8] = S.H[5];
+      R_.p[0] = S.p[0]; R_.p[1] = S.p[1]; R_.p[2] = S.p[2];
+      R_.iters = S.iters; R_.evals = S.evals;
+      R_.ref_evals = S.ref_evals + 1;       // + the getHessian pass (src/PoseEstimator.cpp:56)
+      R_.converged = S.converged;
+      R_.status = aborted ? NDT_E_HIP : (n > 0 ? NDT_OK : NDT_E_ARG);
+      R_.pad_ = 0;
+      R_.kbar = (S.evals > 0 && n > 0) ? S.pairs / ((double)S.evals * (double)n) : 0.0;
+      results[b] = R_;
+      if (allow_helpers) {
+        st64(&C->ticket, (u64)kEpochDone << 32);
+        __hip_atomic_fetch_add(&hdr->done, 1u, NDT_RLX, NDT_AGENT);
+      }
+      if (prof) {
+        prof[8 * b + 0] = t_eval; prof[8 * b + 1] = t_adv | (t_fit << 32) | ((u64)(L.RG.nspill > 0) << 63); prof[8 * b + 2] = (t_first_shared << 32) | (t_scan0 & 0xFFFFFFFFull);
+        prof[8 * b + 3] = (unsigned long long)S.evals | ((u64)n_shared << 16) | ((u64)n_helped << 32);
+        prof[8 * b + 6] = t_wait; prof[8 * b + 7] = wall_clock64() - t_start;
+        u64 *p2 = prof + 8 * (size_t)B + 8 * (size_t)b;
+        p2[0] = a_n; p2[1] = a_pro; p2[2] = a_own; p2[3] = a_wait; p2[4] = a_comb; p2[5] = a_adv;
+      }
+    }
+      // next scan of the batch, if any
+    __syncthreads();
+    if (threadIdx.x == 0) L.sflag[3] = (int)gridDim.x + (int)__hip_atomic_fetch_add(&hdr->next, 1u, NDT_RLX, NDT_AGENT);
+    __syncthreads();
+    b = L.sflag[3];
+  }
+
+  // ============================================ helper ============================================
+  if (!allow_helpers || aborted) return;
+  u64 idle_ticks = 400;
+  for (unsigned rounds = 0; rounds < 0x40000000u; ++rounds) {
+    // ---- find an unfinished scan that still has room for a helper ----
+    __syncthreads();
+    if (threadIdx.x == 0) { L.sflag[0] = INT_MAX; L.sflag[3] = 0; }
+    __syncthreads();
+    const int start = (int)((blockIdx.x * 97u) % (unsigned)B);
+    // helpers per scan: as many as the unfinished scans leave workgroups for (the last stragglers get
+    // up to kMaxHelpers, a unit each per wave)
+    const int unfinished = max(1, B - (int)ld32(&hdr->done));
+    const int room = min(allow_helpers, max(min(allow_helpers, kBaseHelpers), (int)gridDim.x / unfinished - 1));
+    for (int k = threadIdx.x; k < B; k += kBlock) {
+      int b = start + k; if (b >= B) b -= B;
+      const u32 ep = (u32)(rd64_fresh(&ctl[b].ticket) >> 32);
+      if (ep == 0u || ep == kEpochDone) continue;
+      const u32 h = rd32_fresh(&ctl[b].helpers);
+      if (h >= (u32)room) continue;
+      // a scan that already needed many passes will likely need many more: most passes first,
+      // each attached helper counting like 4 passes fewer; then nearest
+      const int score = (int)min(ld32(&ctl[b].passes), 200u) - NDT_HELPER_PENALTY * (int)h;
+      atomicMin(&L.sflag[0], (int)(((u32)(512 - score) << 20) | (u32)k));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int code = -1;                                       // -1: nothing joinable right now
+      unsigned polls = 63;
+      if (ld32(&hdr->done) >= (u32)B || watchdog(hdr, t_start, polls)) code = -2;   // -2: leave
+      else if (L.sflag[0] != INT_MAX) {
+        int b = start + (L.sflag[0] & 0xFFFFF); if (b >= B) b -= B;
+        const u32 h = __hip_atomic_fetch_add(&ctl[b].helpers, 1u, NDT_RLX, NDT_AGENT);
+        if (h >= (u32)room) {
+          __hip_atomic_fetch_sub(&ctl[b].helpers, 1u, NDT_RLX, NDT_AGENT);   // lost the race: look again
+        } else {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // geometry + ordered copy of the owner
+          drain_vmem();
+          if (prof && h == 0) prof[8 * b + 4] = wall_clock64() - t_start;
+          code = b;
+        }
+      }
+      L.sflag[3] = code;
+      if (code == -1) {                                    // back off: 4 us, doubling up to NDT_IDLE_MAX ticks
+        const u64 t0 = wall_clock64();
+        while (wall_clock64() - t0 < idle_ticks) __builtin_amdgcn_s_sleep(64);
+        if (idle_ticks < NDT_IDLE_MAX) idle_ticks *= 2;
+      } else {
+        idle_ticks = 400;
+      }
+    }
+    __syncthreads();
+    const int vb = L.sflag[3];
+    if (vb == -2) break;
+    if (vb < 0) continue;
+    // ---- attached to scan vb: stage its window, register, then serve its epochs until it is done ----
+    ScanCtl *C = ctl + vb;
+    const u64 o0 = shared_scan ? offsets[0] : offsets[vb];
+    const u64 o1 = shared_scan ? offsets[1] : offsets[vb + 1];
+    const int n = (int)(o1 - o0);
+    if (threadIdx.x == 0) { L.sflag[1] = (int)C->use_sorted; L.sflag[0] = (int)C->owner_wg; }
+    if (threadIdx.x == 0) {
+      Region r; r.x0 = C->region[0]; r.y0 = C->region[1]; r.rw = C->region[2]; r.rh = C->region[3];
+      r.cap = C->region[4]; r.nspill = C->region[5];
+      L.RG = r;
+    }
+    {
+      unsigned *wmap = reinterpret_cast<unsigned *>(L.wpart);
+      const unsigned *gw = wantmap + (size_t)vb * (kRegionCells / 32);
+      for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) wmap[i] = gw[i];
+    }
+    if (threadIdx.x == 0) L.sflag[2] = (int)ld32(&C->phase);
+    __syncthreads();
+    const int owner_wg = L.sflag[0];
+    const float2 *pts = L.sflag[1] ? (shared_scan ? sorted + (size_t)owner_wg * (size_t)n : sorted + o0)
+                                   : (reinterpret_cast<const float2 *>(scans) + o0);
+    if (L.sflag[2] == 0) fill_window(M, L, pool);          // a scan in its fitness pass needs no window
+    const Window W = window_of(L.RG, pool);
+    if (prof && threadIdx.x == 0 && prof[8 * vb + 5] == 0) prof[8 * vb + 5] = wall_clock64() - t_start;
+    u64 *vtot = utot + (size_t)vb * kUnits * 12;
+    // register: from now on this workgroup does nothing but watch the scan's epoch word
+    if (threadIdx.x == 0) L.hrank = (int)__hip_atomic_fetch_add(&C->ready, 1u, NDT_RLX, NDT_AGENT);
+    __syncthreads();
+    const int rank = L.hrank;
+    u32 last_ep = 0;
+    for (unsigned turns = 0; turns < 0x40000000u; ++turns) {         // counted (tools/repro/ticket2.hip)
+      if (wave == 0) {
+        // wave 0 polls the epoch word (one load in flight per helper workgroup on the owner's line)
+        u64 word = 0;
+        if (lane == 0) {
+          unsigned polls = 0;
+          for (unsigned it = 0; it < 0x40000000u; ++it) {
+            word = ld64(&C->ticket);
+            if ((u32)(word >> 32) != last_ep && (u32)(word >> 32) != 0u) break;
+            if (watchdog(hdr, t_start, polls)) { word = (u64)kEpochDone << 32; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+        }
+        word = wave_bcast64(word);
+        const int h = (int)((word >> 16) & 0xFFu);
+        if ((u32)(word >> 32) != kEpochDone && rank < h && lane < 6) L.hpose[lane] = ld64(&C->pose[lane]);   // stable: this helper is counted in
+        if (lane == 0) { L.hword = word; L.jnext = 0; }
+      }
+      __syncthreads();
+      const u64 word = L.hword;
+      const u32 ep = (u32)(word >> 32);
+      if (ep == kEpochDone) break;
+      last_ep = ep;
+      const int h = (int)((word >> 16) & 0xFFu), ubeg = (int)(word & 0xFFu), uend = (int)((word >> 8) & 0xFFu);
+      int done_units = 0;
+      if (rank < h) {
+        PassPose pp;
+        const u64 w0 = L.hpose[0], w1 = L.hpose[1];
+        pp.T.c = __uint_as_float((u32)w0); pp.T.s = __uint_as_float((u32)(w0 >> 32));
+        pp.T.tx = __uint_as_float((u32)w1); pp.T.ty = __uint_as_float((u32)(w1 >> 32));
+        pp.cj = __longlong_as_double((long long)L.hpose[2]); pp.sj = __longlong_as_double((long long)L.hpose[3]);
+        pp.ch = __longlong_as_double((long long)L.hpose[4]); pp.sh = __longlong_as_double((long long)L.hpose[5]);
+        pp.kind = (int)((word >> 24) & 0xFFu);
+        double *wt = L.wtmp + wave * 12;
+        for (int it = 0; it <= kUnits; ++it) {               // this workgroup's units, handed out from an LDS counter
+          int j = 0;
+          if (lane == 0) j = atomicAdd(&L.jnext, 1);
+          j = __builtin_amdgcn_readfirstlane(j);
+          const int u = ubeg + (rank + 1) + j * (h + 1);
+          if (u >= uend) break;
+          unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, u % kWaves, u / kWaves, u / kWaves + 1, wt, 0);
+          if (lane < 12) st64(&vtot[u * 12 + lane], (u64)__double_as_longlong(wt[lane]));
+        }
+        drain_vmem();                                        // the whole wave: its stores have landed
+        const int total = uend - ubeg;
+        done_units = (total - (rank + 1) + h) / (h + 1);     // units ubeg + rank+1 + j*(h+1) below uend
+        if (done_units < 0) done_units = 0;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0 && done_units > 0) __hip_atomic_fetch_add(&C->arrive, (u32)done_units, NDT_RLX, NDT_AGENT);
+    }
+  }
+}
+
+// One derivative pass at an explicit pose (tests / profiling): grid-stride over points,
+// one partial record per workgroup, summed on the host in block order.
+template <bool SSE, bool INCL>
+__global__ void __launch_bounds__(256)
+ndt_eval_kernel(MapView M, double snap, const float *__restrict__ scan, size_t stride, int n,
+                double p0, double p1, double p2, double *__restrict__ partial /* grid x kAcc */) {
+  __shared__ double sred[(4 + 1) * kAcc];
+  __shared__ double etab[64];
+  __shared__ unsigned short no_slot[16];
+  __shared__ CellEntry no_ent[1];
+  if (threadIdx.x < 64) etab[threadIdx.x] = c_exp2_tab[threadIdx.x];
+  if (threadIdx.x < 16) no_slot[threadIdx.x] = 0;
+  if (threadIdx.x == 0) { no_ent[0].cent = make_float2(INFINITY, INFINITY); no_ent[0].mx = no_ent[0].my = 0; no_ent[0].i00 = no_ent[0].i01 = no_ent[0].i11 = 0; }
+  __syncthreads();
+  double p[3] = {p0, p1, p2};
+  Tf32 T = tf_from_p(p);
+  double cj, sj;
+  angle_cs(snap, p2, cj, sj);
+  Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
+  Window W;
+  W.R = Region{0, 0, 0, 0, 0, 0}; W.slot = no_slot; W.ent = no_ent;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float2 pt = load_pt(scan, stride, i);
+    eval_point<SSE, INCL>(M, W, etab, T, pt.x, pt.y, cj, sj, cj, sj, A);
+  }
+  block_reduce_acc(A, sred, sred + 4 * kAcc);
+  if (threadIdx.x < kAcc) partial[blockIdx.x * kAcc + threadIdx.x] = sred[4 * kAcc + threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256)
+ndt_fitness_kernel(MapView M, const float *__restrict__ scan, size_t stride, int n, Tf32 T,
+                   double *__restrict__ partial /* grid x 2 */) {
+  __shared__ double sred[(4 + 1) * 2];
+  double fsum = 0.0, fcnt = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float2 pt = load_pt(scan, stride, i);
+    float qx, qy;
+    tf_apply(T, M.transform_sse, pt.x, pt.y, qx, qy);
+    if (!finite2(qx, qy)) continue;
+    float best = nearest_sq(M, qx, qy);
+    if (best < INFINITY) { fsum += (double)best; fcnt += 1.0; }
+  }
+  block_reduce2(fsum, fcnt, sred, sred + 4 * 2);
+  if (threadIdx.x < 2) partial[blockIdx.x * 2 + threadIdx.x] = sred[4 * 2 + threadIdx.x];
+}
