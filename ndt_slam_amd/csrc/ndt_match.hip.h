@@ -523,11 +523,12 @@ __device__ __forceinline__ void unit_sums(const MapView &M, const Window &W, con
   }
 }
 
-// Bound on every spin: looked at once per 64 polls (the abort word is one line shared by the chip).
-__device__ __forceinline__ bool watchdog(WsHeader *hdr, u64 t_start, unsigned &polls) {
+// Bound on every spin, measured from the start of that spin (a launch may legitimately run longer
+// than any bound); looked at once per 64 polls (the abort word is one line shared by the chip).
+__device__ __forceinline__ bool watchdog(WsHeader *hdr, u64 spin_start, unsigned &polls) {
   if ((++polls & 63u) != 0u) return false;
   if (ld32(&hdr->abort)) return true;
-  if (wall_clock64() - t_start > kWatchTicks) { st32(&hdr->abort, 1u); return true; }
+  if (wall_clock64() - spin_start > kWatchTicks) { st32(&hdr->abort, 1u); return true; }
   return false;
 }
 
@@ -705,7 +706,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
             int bad = 0; unsigned polls = 0;
             const u64 w0 = wall_clock64();
             while (ld32(&C->arrive) < need) {
-              if (watchdog(hdr, t_start, polls)) { bad = 1; break; }
+              if (watchdog(hdr, w0, polls)) { bad = 1; break; }
               __builtin_amdgcn_s_sleep(2);
             }
             t_wait += wall_clock64() - w0;
@@ -821,8 +822,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     __syncthreads();
     if (threadIdx.x == 0) {
       int code = -1;                                       // -1: nothing joinable right now
-      unsigned polls = 63;
-      if (ld32(&hdr->done) >= (u32)B || watchdog(hdr, t_start, polls)) code = -2;   // -2: leave
+      if (ld32(&hdr->done) >= (u32)B || ld32(&hdr->abort)) code = -2;                // -2: leave
       else if (L.sflag[0] != INT_MAX) {
         int b = start + (L.sflag[0] & 0xFFFFF); if (b >= B) b -= B;
         const u32 h = __hip_atomic_fetch_add(&ctl[b].helpers, 1u, NDT_RLX, NDT_AGENT);
@@ -884,10 +884,11 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         u64 word = 0;
         if (lane == 0) {
           unsigned polls = 0;
+          const u64 w0 = wall_clock64();
           for (unsigned it = 0; it < 0x40000000u; ++it) {
             word = ld64(&C->ticket);
             if ((u32)(word >> 32) != last_ep && (u32)(word >> 32) != 0u) break;
-            if (watchdog(hdr, t_start, polls)) { word = (u64)kEpochDone << 32; break; }
+            if (watchdog(hdr, w0, polls)) { word = (u64)kEpochDone << 32; break; }
             __builtin_amdgcn_s_sleep(1);
           }
         }
