@@ -59,12 +59,23 @@ def scatter_batch(scans, offsets, inits, src=0, device="cpu"):
     return t_sc.cpu().numpy(), t_of.cpu().numpy().astype(np.uint64), t_in.cpu().numpy()
 
 
+_GATHER_OK = True
+
+
 def gather_results(res_bytes, dst=0):
     """Gather equally sized uint8 result tensors to rank `dst` (returns the list there, else None)."""
     world, rank = dist.get_world_size(), dist.get_rank()
     out = [torch.empty_like(res_bytes) for _ in range(world)] if rank == dst else None
-    dist.gather(res_bytes, out, dst=dst)
-    return out
+    global _GATHER_OK
+    if _GATHER_OK:
+        try:
+            dist.gather(res_bytes, out, dst=dst)
+            return out
+        except (RuntimeError, NotImplementedError):     # a backend without gather: every rank gets all records
+            _GATHER_OK = False
+    full = [torch.empty_like(res_bytes) for _ in range(world)]
+    dist.all_gather(full, res_bytes)
+    return full if rank == dst else None
 
 
 def best_hypothesis(scores, first_index, device="cpu"):
