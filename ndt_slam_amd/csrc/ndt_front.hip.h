@@ -75,6 +75,165 @@ prefilter_kernel(const float *__restrict__ xy, size_t stride, const unsigned lon
   }
 }
 
+// The same machine on kPfWaves waves per scan.  The 512 slots are independent state machines; wave w
+// owns the slots with (slot mod kPfWaves) == w.  Every wave reads the whole scan 64 points at a
+// time (cheap: load, hash, ballot), queues the points of its own slots in order, and replays a
+// step whenever 64 are queued -- so the expensive part (turn-taking on the slot state) runs on a
+// quarter of the points per wave.  A flush is stored at the index of the point that caused it
+// (sparse copy) with a bit in an LDS bitmap; a prefix sum over the bitmap then writes the flushes in
+// the order of those indices, which is the order the sequential filter emits them in.
+constexpr int kPfWaveBits = 2, kPfWaves = 1 << kPfWaveBits, kPfQueue = 128, kPfMaxPoints = 1 << 18;   // bitmap: 32 KiB of LDS
+__global__ void __launch_bounds__(64 * kPfWaves)
+prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
+                    float leaf, float2 *__restrict__ sparse /* at the raw offsets */,
+                    float2 *__restrict__ tmp /* at the raw offsets: dense result */, unsigned *__restrict__ counts) {
+  __shared__ PfSlot slot[kPfSlots];
+  __shared__ float2 qpt[kPfWaves][kPfQueue];
+  __shared__ int qidx[kPfWaves][kPfQueue];
+  __shared__ unsigned fbits[kPfMaxPoints / 32];
+  __shared__ int wsum[kPfWaves + 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const float inv = 1.0f / leaf;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const unsigned long long o0 = offsets[b];
+    const int n = (int)(offsets[b + 1] - o0);
+    __syncthreads();
+    for (int h = threadIdx.x; h < kPfSlots; h += 64 * kPfWaves) { PfSlot z; z.ix = 0; z.iy = 0; z.cnt = 0; z.cx = 0.f; z.cy = 0.f; z.pad = 0; slot[h] = z; }
+    const int nwords = (min(n, kPfMaxPoints) + 31) / 32;
+    for (int i = threadIdx.x; i < nwords; i += 64 * kPfWaves) fbits[i] = 0u;
+    __syncthreads();
+    int nout = 0;
+    if (n <= kPfMaxPoints) {
+      // replay of one step: `cnt` queued points of this wave's slots, in point order
+      auto replay = [&](int cnt) {
+        const bool active = lane < cnt;
+        const float2 p = active ? qpt[w][lane] : make_float2(0.f, 0.f);
+        const int i = active ? qidx[w][lane] : 0;
+        const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
+        const unsigned h = ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);
+        unsigned long long peers = __ballot(active);
+#pragma unroll
+        for (int bit = kPfWaveBits; bit < 9; ++bit) {     // the low bits are this wave's number
+          const unsigned long long one = __ballot(active && ((h >> bit) & 1u));
+          peers &= ((h >> bit) & 1u) ? one : ~one;
+        }
+        const int rank = __builtin_popcountll(peers & lt);
+        for (int turn = 0; turn < 64; ++turn) {
+          if (!__ballot(active && rank >= turn)) break;
+          if (active && rank == turn) {
+            PfSlot e = slot[h];
+            if (e.cnt && (ix != e.ix || iy != e.iy)) {
+              sparse[o0 + (unsigned long long)i] = make_float2(e.cx / (float)e.cnt, e.cy / (float)e.cnt);
+              atomicOr(&fbits[i >> 5], 1u << (i & 31));
+              e.cnt = 0; e.cx = 0.f; e.cy = 0.f;
+            }
+            e.ix = ix; e.iy = iy; e.cnt += 1; e.cx += p.x; e.cy += p.y;
+            slot[h] = e;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+      };
+      int qn = 0;
+      float2 pnext = make_float2(0.f, 0.f);
+      if (lane < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)lane);
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const float2 p = pnext;
+        if (i + 64 < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)(i + 64));
+        const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
+        const unsigned h = ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);
+        const bool mine = i < n && (int)(h & (unsigned)(kPfWaves - 1)) == w;
+        const unsigned long long mb = __ballot(mine);
+        if (mine) { const int pos = qn + __builtin_popcountll(mb & lt); qpt[w][pos] = p; qidx[w][pos] = i; }
+        qn += __builtin_popcountll(mb);
+        __builtin_amdgcn_wave_barrier();
+        if (qn >= 64) {
+          replay(64);
+          const int rest = qn - 64;                           // < 64: move the tail to the front
+          float2 tp = make_float2(0.f, 0.f); int ti = 0;
+          if (lane < rest) { tp = qpt[w][64 + lane]; ti = qidx[w][64 + lane]; }
+          __builtin_amdgcn_wave_barrier();
+          if (lane < rest) { qpt[w][lane] = tp; qidx[w][lane] = ti; }
+          __builtin_amdgcn_wave_barrier();
+          qn = rest;
+        }
+      }
+      if (qn > 0) replay(qn);
+      __syncthreads();
+      // flushes in the order of the points that caused them: prefix sum over the bitmap
+      int mine_cnt = 0;
+      const int per = (nwords + 64 * kPfWaves - 1) / (64 * kPfWaves);
+      const int w0 = min((int)threadIdx.x * per, nwords), w1 = min(w0 + per, nwords);
+      for (int k = w0; k < w1; ++k) mine_cnt += __builtin_popcount(fbits[k]);
+      int incl = mine_cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      if (lane == 63) wsum[w] = incl;
+      __syncthreads();
+      int off = incl - mine_cnt;
+      for (int k = 0; k < w; ++k) off += wsum[k];
+      int total = 0;
+      for (int k = 0; k < kPfWaves; ++k) total += wsum[k];
+      for (int k = w0; k < w1; ++k) {
+        unsigned bits = fbits[k];
+        while (bits) {
+          const int bpos = __builtin_ctz(bits); bits &= bits - 1;
+          tmp[o0 + (unsigned long long)off] = sparse[o0 + (unsigned long long)(k * 32 + bpos)];
+          ++off;
+        }
+      }
+      nout = total;
+      __syncthreads();
+    } else if (w == 0) {
+      // a scan too long for the bitmap: one wave, the plain replay
+      float2 pnext = make_float2(0.f, 0.f);
+      if (lane < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)lane);
+      for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        const bool active = i < n;
+        const float2 p = pnext;
+        if (i + 64 < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)(i + 64));
+        const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
+        const unsigned h = ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);
+        unsigned long long peers = __ballot(active);
+#pragma unroll
+        for (int bit = 0; bit < 9; ++bit) {
+          const unsigned long long one = __ballot(active && ((h >> bit) & 1u));
+          peers &= ((h >> bit) & 1u) ? one : ~one;
+        }
+        const int rank = __builtin_popcountll(peers & lt);
+        bool flushed = false; float fx = 0.f, fy = 0.f;
+        for (int turn = 0; turn < 64; ++turn) {
+          if (!__ballot(active && rank >= turn)) break;
+          if (active && rank == turn) {
+            PfSlot e = slot[h];
+            if (e.cnt && (ix != e.ix || iy != e.iy)) { flushed = true; fx = e.cx / (float)e.cnt; fy = e.cy / (float)e.cnt; e.cnt = 0; e.cx = 0.f; e.cy = 0.f; }
+            e.ix = ix; e.iy = iy; e.cnt += 1; e.cx += p.x; e.cy += p.y;
+            slot[h] = e;
+          }
+          __builtin_amdgcn_wave_barrier();
+        }
+        const unsigned long long fb = __ballot(flushed);
+        if (flushed) tmp[o0 + (unsigned long long)(nout + __builtin_popcountll(fb & lt))] = make_float2(fx, fy);
+        nout += __builtin_popcountll(fb);
+      }
+    }
+    __syncthreads();
+    if (w == 0) {                                            // what is left, in slot order
+      if (n > kPfMaxPoints) nout = __builtin_amdgcn_readfirstlane(nout);
+      for (int h0 = 0; h0 < kPfSlots; h0 += 64) {
+        const PfSlot e = slot[h0 + lane];
+        const unsigned long long fb = __ballot(e.cnt > 0);
+        if (e.cnt > 0) tmp[o0 + (unsigned long long)(nout + __builtin_popcountll(fb & lt))] =
+            make_float2(e.cx / (float)e.cnt, e.cy / (float)e.cnt);
+        nout += __builtin_popcountll(fb);
+      }
+      if (lane == 0) counts[b] = (unsigned)nout;
+    }
+  }
+}
+
 // offsets of the filtered scans: exclusive scan of the counts (one workgroup)
 __global__ void __launch_bounds__(1024)
 prefilter_offsets_kernel(const unsigned *__restrict__ counts, int B, unsigned long long *__restrict__ out_offsets) {

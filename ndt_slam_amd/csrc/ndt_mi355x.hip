@@ -692,11 +692,16 @@ int ndt_prefilter_batch_dev(ndt_ctx *ctx, const float *raw_xy, size_t stride, co
   int rc;
   // filtered points at the raw offsets, then the per-scan counts
   const size_t tmp_bytes = total_raw_points * sizeof(float2);
-  if ((rc = ensure(ctx, &ctx->d_pf, &ctx->d_pf_cap, tmp_bytes + (size_t)B * sizeof(unsigned)))) return rc;
-  float2 *tmp = (float2 *)ctx->d_pf;
-  unsigned *counts = (unsigned *)((char *)ctx->d_pf + tmp_bytes);
+  if ((rc = ensure(ctx, &ctx->d_pf, &ctx->d_pf_cap, 2 * tmp_bytes + (size_t)B * sizeof(unsigned)))) return rc;
+  float2 *tmp = (float2 *)ctx->d_pf;                                   // dense result at the raw offsets
+  float2 *sparse = (float2 *)((char *)ctx->d_pf + tmp_bytes);          // flushes at the index of their cause
+  unsigned *counts = (unsigned *)((char *)ctx->d_pf + 2 * tmp_bytes);
   const int grid = B < 8 * ctx->num_cus ? B : 8 * ctx->num_cus;
-  prefilter_kernel<<<grid, 64, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf, tmp, counts);
+  if (getenv("NDT_PREFILTER_1WAVE"))     // diagnostic: the one-wave-per-scan kernel
+    prefilter_kernel<<<grid, 64, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf, tmp, counts);
+  else
+    prefilter_mw_kernel<<<grid, 64 * kPfWaves, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf,
+                                                        sparse, tmp, counts);
   prefilter_offsets_kernel<<<1, 1024, 0, st>>>(counts, B, (unsigned long long *)out_offsets);
   const int gx = (int)std::min<size_t>(64, (total_raw_points / (size_t)B + 255) / 256 + 1);
   prefilter_pack_kernel<<<dim3((unsigned)gx, (unsigned)std::min(B, 65535)), 256, 0, st>>>(
