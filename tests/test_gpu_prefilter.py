@@ -34,6 +34,14 @@ def test_prefilter_matches_oracle_bit_for_bit(gpu, oracle, leaf):
             assert got.tobytes() == ref.tobytes()
 
 
+def test_prefilter_scan_longer_than_the_flush_bitmap(gpu, oracle):
+    """More than 2^18 points in one scan: the kernel's single-wave path."""
+    capi, ctx = gpu
+    rng = np.random.default_rng(17)
+    cloud = lidar_like(rng, 300_000, radius=60.0)
+    assert ctx.prefilter(cloud, 0.05).tobytes() == oracle.approx_voxel_filter(cloud, 0.05).tobytes()
+
+
 def test_prefilter_edge_cases(gpu, oracle):
     capi, ctx = gpu
     one_voxel = np.full((300, 2), 0.012, np.float32) + np.linspace(0, 1e-3, 300, dtype=np.float32)[:, None]
