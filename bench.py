@@ -220,6 +220,34 @@ def main():
         out["prefilter"] = {"scans": B, "raw_points": int(len(raw)), "filtered_points": n_out, "leaf": 0.05, "ms": ms,
                             "raw_points_per_s": len(raw) / (ms * 1e-3),
                             "algorithmic_GBps": (len(raw) + n_out) * 8 / (ms * 1e-3) / 1e9}
+        # a whole front-end step for the batch without leaving the device (rows f2 + f1 + a2 + a3-a9 + f2):
+        # odometry prediction -> pre-filter -> map rebuild -> matches -> EKF fusion
+        pred0 = np.column_stack([inits[:, 0], inits[:, 1], np.degrees(inits[:, 2])])
+        d_last = torch.from_numpy(pred0).to(dev); d_prevo = torch.zeros(B, 3, dtype=torch.float64, device=dev)
+        d_curo = torch.zeros_like(d_prevo)                       # zero odometry motion: prediction = last pose
+        d_mo = torch.zeros_like(d_prevo); d_pred = torch.zeros_like(d_prevo); d_in2 = torch.zeros_like(d_prevo)
+        d_lc = torch.from_numpy(np.tile(np.eye(3).ravel() * 1e-4, (B, 1))).to(dev)
+        d_fu = torch.zeros_like(d_prevo); d_cv = torch.zeros(B, 9, dtype=torch.float64, device=dev)
+        d_ok = torch.zeros(B, dtype=torch.int32, device=dev)
+        fprm = capi.default_fuse_params(score_thre=0.5)
+        ts = []
+        for _ in range(5):
+            e0.record(stream)
+            ctx.predict_batch_dev(d_curo.data_ptr(), d_prevo.data_ptr(), d_last.data_ptr(), B, d_mo.data_ptr(),
+                                  d_pred.data_ptr(), d_in2.data_ptr(), stream=stream.cuda_stream)
+            ctx.prefilter_batch_dev(d_raw.data_ptr(), 8, d_roff.data_ptr(), B, len(raw), 0.05, d_f.data_ptr(),
+                                    d_foff.data_ptr(), stream=stream.cuda_stream)
+            gmap.rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
+            gmap.align_batch_dev(d_f.data_ptr(), d_foff.data_ptr(), B, len(raw), d_in2.data_ptr(), d_res2[0].data_ptr(),
+                                 stream=stream.cuda_stream)
+            ctx.fuse_batch_dev(d_res2[0].data_ptr(), d_pred.data_ptr(), d_mo.data_ptr(), d_last.data_ptr(), d_lc.data_ptr(), B,
+                               fprm, d_fu.data_ptr(), d_cv.data_ptr(), d_ok.data_ptr(), stream=stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        out["front_end_step"] = {"stages": "predict + pre-filter + map rebuild + match + fuse, all on the device",
+                                 "scans": B, "raw_points_per_scan": int(len(raw) // B), "ms": float(np.median(ts)),
+                                 "scans_per_s": B / (float(np.median(ts)) * 1e-3), "accepted": int(d_ok.sum().item())}
 
     # CPU baseline: the oracle (a port -- PCL itself is absent) on this box's host cores,
     # rank 0 at N = 1 only, on a bounded sample of the same batch.

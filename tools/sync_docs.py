@@ -20,6 +20,7 @@ s = s[:a] + f"""Round-1 numbers (1 × MI355X, `profiles/r01_bench.json`):
 | one scan (configs[1]) | {d['single_scan_ms']:.3f} ms |
 | roofline | {d['roofline']['achieved']:.0f} GB/s algorithmic, frac {d['roofline']['frac']:.3f}; measured traffic {t['bytes_per_launch']/1e9:.2f} GB per launch (FETCH + WRITE, raw) |
 | source pre-filter (row f1) | 256 scans × 30k raw points in {d['prefilter']['ms']:.2f} ms ({d['prefilter']['raw_points_per_s']/1e9:.1f} G points/s) |
+| whole front-end step | predict → pre-filter → map rebuild → match → fuse for 256 raw scans of 30k points, all on the device: {d['front_end_step']['ms']:.2f} ms ({d['front_end_step']['scans_per_s']/1e3:.0f}k scans/s) |
 | CPU baseline | oracle (port), 1 thread: {cb['value']:.1f} matches/s; {cb['all_cores']['cores']} threads: {cb['all_cores']['value']:.0f} matches/s |
 | parity on the bench sample | max |Δpos| = {d['parity']['max_dpos_m']} m, max |Δyaw| = {d['parity']['max_dyaw_rad']} rad, identical iteration counts ({d['parity']['sample']} scans) |
 
