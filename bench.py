@@ -174,6 +174,9 @@ def main():
                        "resolution": cfg["resolution"], "parallelism": "scan-shards x%d, gather of results" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "note": "achieved = SURVEY 8d algorithmic bytes / kernel time.  The kernel is VALU-issue bound, "
+                                 "not HBM bound: each voxel record is staged once per match in LDS, so the measured HBM "
+                                 "traffic is below the algorithmic bytes (DESIGN.md 4.7)",
                          "kernel": "ndt_align_kernel", "kernel_ms": avg_kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "mean_evals": float(res["evals"].mean()), "max_evals": int(res["evals"].max()),
