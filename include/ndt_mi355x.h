@@ -96,7 +96,7 @@ int ndt_default_params(ndt_params *p);
 
 /* One context per process and device (one process per GPU).  device = HIP ordinal. */
 int ndt_ctx_create(int device, ndt_ctx **out);
-int ndt_ctx_destroy(ndt_ctx *ctx);
+int ndt_ctx_destroy(ndt_ctx *ctx);               /* destroy the context's maps first */
 const char *ndt_last_error(const ndt_ctx *ctx);   /* ctx may be NULL: last global error */
 void *ndt_ctx_stream(ndt_ctx *ctx);               /* hipStream_t the context works on   */
 /* Make the context work on a caller-owned hipStream_t (e.g. the stream a host framework already

@@ -6,6 +6,7 @@ library or a missing GPU raises.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -203,6 +204,9 @@ class Context:
             self.h = C.c_void_p()
 
     def __del__(self):
+        # at interpreter shutdown the HIP runtime may already be gone: leave the handles to the OS
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -295,6 +299,8 @@ class Map:
             self.h = C.c_void_p()
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
