@@ -801,7 +801,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
   for (unsigned rounds = 0; rounds < 0x40000000u; ++rounds) {
     // ---- find an unfinished scan that still has room for a helper ----
     __syncthreads();
-    if (threadIdx.x == 0) { L.sflag[0] = INT_MAX; L.sflag[3] = 0; }
+    if (threadIdx.x == 0) { L.sflag[0] = INT_MAX; L.sflag[3] = 0; L.sflag[2] = 0; }
     __syncthreads();
     const int start = (int)((blockIdx.x * 97u) % (unsigned)B);
     // helpers per scan: as many as the unfinished scans leave workgroups for (the last stragglers get
@@ -811,7 +811,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     for (int k = threadIdx.x; k < B; k += kBlock) {
       int b = start + k; if (b >= B) b -= B;
       const u32 ep = (u32)(rd64_fresh(&ctl[b].ticket) >> 32);
-      if (ep == 0u || ep == kEpochDone) continue;
+      if (ep == 0u) { L.sflag[2] = 1; continue; }          // not open yet (owner still setting up): may need help later
+      if (ep == kEpochDone) continue;
       const u32 h = rd32_fresh(&ctl[b].helpers);
       if (h >= (u32)room) continue;
       // a scan that already needed many passes will likely need many more: most passes first,
@@ -823,6 +824,9 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     if (threadIdx.x == 0) {
       int code = -1;                                       // -1: nothing joinable right now
       if (ld32(&hdr->done) >= (u32)B || ld32(&hdr->abort)) code = -2;                // -2: leave
+      // nothing to join, every open scan already has the most helpers a scan can get, none is still to
+      // open: no work can come any more -- leave, so that the CU is free for whatever is queued next
+      else if (L.sflag[0] == INT_MAX && L.sflag[2] == 0 && room >= allow_helpers) code = -2;
       else if (L.sflag[0] != INT_MAX) {
         int b = start + (L.sflag[0] & 0xFFFFF); if (b >= B) b -= B;
         const u32 h = __hip_atomic_fetch_add(&ctl[b].helpers, 1u, NDT_RLX, NDT_AGENT);

@@ -500,7 +500,8 @@ int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, co
   if (!map || !scans || !offsets || !inits || !out || B <= 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: bad arguments");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
-  if (st != ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->evm1, 0));   // the map build may still be running on the context's stream
+  // the map build may still be running on the stream of the context that built the map
+  if (map->ctx && st != map->ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(st, map->ctx->evm1, 0));
   float2 *sorted = nullptr;
   if (total_points > 0) {                      // shared scan: one slot of the scan's size per workgroup
     int rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (shared_scan ? (size_t)ctx->num_cus : (size_t)1) * total_points * 8);
