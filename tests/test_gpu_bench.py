@@ -31,4 +31,5 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
     assert d["value"] > 100 * c["value"]
+    assert 0 < d["map_build_ms"] < d["ms_per_step"]
     assert d["parity"]["max_dpos_m"] <= 1e-4 and d["parity"]["max_dyaw_rad"] <= 1e-4
