@@ -139,10 +139,10 @@ def main():
         # a3-a9 for the whole batch: one launch on `stream`, after this step's build (the library waits
         # for it too; waiting here keeps that wait out of the kernel's event interval)
         stream.wait_event(ev_m[2 * i + 1])
-        ev_a[2 * i].record(stream)
         out = d_res2[i & 1]
         if world > 1:
-            stream.wait_event(ev_done[i & 1])          # its previous gather has finished
+            stream.wait_event(ev_done[i & 1])          # the gather that last read this result buffer has finished
+        ev_a[2 * i].record(stream)
         gm.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, len(scans), d_init.data_ptr(),
                            out.data_ptr(), stream=stream.cuda_stream)
         ev_a[2 * i + 1].record(stream)
