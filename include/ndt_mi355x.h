@@ -205,8 +205,7 @@ int ndt_fuse_batch_dev(ndt_ctx *ctx, const ndt_result *results_dev, const double
  * (include/ndt_slam/PCFilter.h:29-56, called from Submap::makeMap, src/PointCloudMap.cpp:27): the points
  * of `base` with no point of `list` closer than thre_neighbor (PCLUtil::distance_points' float32
  * distance, include/ndt_slam/PCLUtil.h:21-23, strict <), in input order, packed as float2.
- * out needs room for n_base points; n_list may be 0.  (PCFilter::difference_extraction, the PCL octree
- * change detector that produces `list`, stays with PCL.) */
+ * out needs room for n_base points; n_list may be 0. */
 int ndt_remove_neighbors(ndt_ctx *ctx, const float *base_xy_host, size_t base_stride_bytes, size_t n_base,
                          const float *list_xy_host, size_t list_stride_bytes, size_t n_list, double thre_neighbor,
                          float *out_xy_host, size_t *n_out);
@@ -214,6 +213,42 @@ int ndt_remove_neighbors(ndt_ctx *ctx, const float *base_xy_host, size_t base_st
 int ndt_remove_neighbors_dev(ndt_ctx *ctx, const float *base_xy_dev, size_t base_stride_bytes, size_t n_base,
                              const float *list_xy_dev, size_t list_stride_bytes, size_t n_list,
                              double thre_neighbor, float *out_xy_dev, uint64_t *n_out_dev, void *stream);
+
+/* SURVEY.md 8f row f3 -- replaces PCFilter::difference_extraction(cloud_base, cloud_test)
+ * (include/ndt_slam/PCFilter.h:58-94): the points of `test` that fall in leaf voxels (side `resol`) of
+ * pcl::octree::OctreePointCloudChangeDetector which hold no point of `base`.  The voxel lattice is the
+ * octree's own: anchored by the first point added (base first, then test) and carried through every
+ * doubling of the bounding box with the keys computed in fp64 as PCL computes them.  z is taken as 0
+ * (PointCloudMap::addPoints, src/PointCloudMap.cpp:71); non-finite points are skipped as PCL skips them.
+ * The points come back in INPUT order, packed as float2; PCL returns the same set in the order of its
+ * depth-first leaf walk, which nothing downstream depends on (the list only feeds remove_neighborPoint).
+ * out needs room for n_test points; n_base may be 0.  NDT_E_ARG when the two clouds span more than 2^30
+ * voxels per axis (PCL's own key width is 32 bits). */
+int ndt_difference_extraction(ndt_ctx *ctx, const float *base_xy_host, size_t base_stride_bytes, size_t n_base,
+                              const float *test_xy_host, size_t test_stride_bytes, size_t n_test, double resol,
+                              float *out_xy_host, size_t *n_out);
+/* Same with device pointers; *n_out_dev is a uint64 in device memory (UINT64_MAX on the span error);
+ * asynchronous on `stream`. */
+int ndt_difference_extraction_dev(ndt_ctx *ctx, const float *base_xy_dev, size_t base_stride_bytes, size_t n_base,
+                                  const float *test_xy_dev, size_t test_stride_bytes, size_t n_test, double resol,
+                                  float *out_xy_dev, uint64_t *n_out_dev, void *stream);
+/* Replaces Submap::makeMap (src/PointCloudMap.cpp:15-39): the submap's cloud from its scans (already in the
+ * map frame), scan i = points [offsets[i], offsets[i+1]) of scans_xy.  With remove_moving: scans[0] when
+ * first_submap (cntS == 0), then for every triple (i, i+1, i+2) the points of scan i+1 that are not within
+ * thre_neighbor of a point of difference_extraction(scan i ++ scan i+2, scan i+1), then the last scan when
+ * `newest`; without: all scans (first submap) or scans 2.. (later ones).  All triples run side by side, one
+ * workgroup each.  out needs room for every input point (twice that for n_scans == 1: the reference then
+ * appends the lone scan as the first and again as the newest).  resol / thre_neighbor are PCFilter's `resol` (0.05) and `thre_neighbor` (0.1),
+ * include/ndt_slam/PCFilter.h:20-23. */
+int ndt_make_map(ndt_ctx *ctx, const float *scans_xy_host, size_t stride_bytes, const uint64_t *offsets, int n_scans,
+                 int first_submap, int newest, int remove_moving, double resol, double thre_neighbor,
+                 float *out_xy_host, size_t *n_out);
+/* Same with the points in device memory (offsets stay on the host); *n_out_dev is a uint64 in device memory
+ * (UINT64_MAX on the span error); asynchronous on `stream`.  The result can be handed to
+ * ndt_prefilter_batch_dev / ndt_map_build_dev without leaving the device. */
+int ndt_make_map_dev(ndt_ctx *ctx, const float *scans_xy_dev, size_t stride_bytes, const uint64_t *offsets,
+                     int n_scans, int first_submap, int newest, int remove_moving, double resol,
+                     double thre_neighbor, float *out_xy_dev, uint64_t *n_out_dev, void *stream);
 
 /* Timing hooks used by bench.py (HIP events on the context's stream; milliseconds of the most
  * recent call of each kind, measured around the kernel launches only). */

@@ -58,6 +58,7 @@ EXPORTS = [
     "ndt_fitness_at", "ndt_last_timing", "ndt_prefilter", "ndt_prefilter_batch_dev",
     "ndt_fuse_default_params", "ndt_predict_batch_dev", "ndt_fuse_batch_dev",
     "ndt_remove_neighbors", "ndt_remove_neighbors_dev",
+    "ndt_difference_extraction", "ndt_difference_extraction_dev", "ndt_make_map", "ndt_make_map_dev",
 ]
 
 
@@ -98,6 +99,11 @@ def lib():
     L.ndt_fuse_batch_dev.argtypes = [vp, vp, vp, vp, vp, vp, i, C.POINTER(FuseParams), vp, vp, vp, vp]
     L.ndt_remove_neighbors.argtypes = [vp, vp, sz, sz, vp, sz, sz, C.c_double, vp, C.POINTER(sz)]
     L.ndt_remove_neighbors_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, C.c_double, vp, vp, vp]
+    L.ndt_difference_extraction.argtypes = [vp, vp, sz, sz, vp, sz, sz, C.c_double, vp, C.POINTER(sz)]
+    L.ndt_difference_extraction_dev.argtypes = [vp, vp, sz, sz, vp, sz, sz, C.c_double, vp, vp, vp]
+    L.ndt_make_map.argtypes = [vp, vp, sz, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp,
+                               C.POINTER(sz)]
+    L.ndt_make_map_dev.argtypes = [vp, vp, sz, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, vp, vp, vp]
     for name in EXPORTS:
         if name not in ("ndt_last_error", "ndt_ctx_stream"):
             getattr(L, name).restype = i
@@ -179,6 +185,38 @@ class Context:
                                               8, len(lst), thre_neighbor, out.ctypes.data, C.byref(m)),
                    "ndt_remove_neighbors")
         return out[:m.value].copy()
+
+    def difference_extraction(self, base, test, resol):
+        """PCFilter::difference_extraction: points of `test` in octree voxels `base` does not occupy (input order)."""
+        base = np.ascontiguousarray(base, dtype=np.float32).reshape(-1, 2)
+        test = np.ascontiguousarray(test, dtype=np.float32).reshape(-1, 2)
+        out = np.empty((len(test) + 1, 2), dtype=np.float32)
+        m = C.c_size_t()
+        self.check(lib().ndt_difference_extraction(self.h, base.ctypes.data if len(base) else None, 8, len(base),
+                                                   test.ctypes.data if len(test) else None, 8, len(test), resol,
+                                                   out.ctypes.data, C.byref(m)), "ndt_difference_extraction")
+        return out[:m.value].copy()
+
+    def make_map(self, scans, first_submap, newest, remove_moving=True, resol=0.05, thre_neighbor=0.1):
+        """Submap::makeMap over a list of (n_i, 2) float32 scans in the map frame -> (n, 2) float32."""
+        scans = [np.ascontiguousarray(s, dtype=np.float32).reshape(-1, 2) for s in scans]
+        off = np.zeros(len(scans) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum([len(s) for s in scans])
+        allp = np.ascontiguousarray(np.concatenate(scans)) if scans else np.zeros((0, 2), np.float32)
+        out = np.empty(((2 if len(scans) == 1 else 1) * len(allp) + 1, 2), dtype=np.float32)
+        m = C.c_size_t()
+        self.check(lib().ndt_make_map(self.h, allp.ctypes.data, 8, off.ctypes.data, len(scans), int(first_submap),
+                                      int(newest), int(remove_moving), resol, thre_neighbor, out.ctypes.data,
+                                      C.byref(m)), "ndt_make_map")
+        return out[:m.value].copy()
+
+    def make_map_dev(self, scans_ptr, stride, offsets, first_submap, newest, remove_moving, resol, thre_neighbor,
+                     out_ptr, n_out_ptr, stream=None):
+        """Device pointers for the points, the result and its uint64 count; `offsets` a host uint64 array."""
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.check(lib().ndt_make_map_dev(self.h, scans_ptr, stride, off.ctypes.data, len(off) - 1, int(first_submap),
+                                          int(newest), int(remove_moving), resol, thre_neighbor, out_ptr, n_out_ptr,
+                                          stream), "ndt_make_map_dev")
 
     def predict_batch_dev(self, odo_cur_ptr, odo_prev_ptr, last_pose_ptr, B, motion_ptr, pred_ptr, init_ptr=None,
                           stream=None):

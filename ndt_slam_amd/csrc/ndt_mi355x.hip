@@ -24,6 +24,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <vector>
 
 #include "ndt_mi355x.h"
 
@@ -40,6 +41,7 @@ thread_local std::string g_last_error;
 #include "ndt_match.hip.h"
 #include "ndt_map_build.hip.h"
 #include "ndt_front.hip.h"
+#include "ndt_localmap.hip.h"
 
 }  // namespace
 
@@ -70,6 +72,9 @@ struct ndt_ctx {
   void *d_ws = nullptr; size_t d_ws_cap = 0;           // WsHeader + ScanCtl[B] + chunk totals
   void *d_pf = nullptr; size_t d_pf_cap = 0;           // pre-filter: filtered points at the raw offsets + counts
   void *d_rn = nullptr; size_t d_rn_cap = 0;           // neighbour removal: block offsets + keep flags
+  void *d_mm = nullptr; size_t d_mm_cap = 0;           // local-map assembly: jobs, pieces, voxel sets, lists
+  void *h_mm = nullptr; size_t h_mm_cap = 0;           // pinned staging of the job table
+  hipEvent_t ev_mm = nullptr; bool mm_pending = false; // job table upload of the previous call
   int num_cus = 0;
   int helpers = 1;                                     // NDT_NO_HELPERS=1 disables work sharing (diagnostic)
 };
@@ -226,6 +231,7 @@ int ndt_ctx_create(int device, ndt_ctx **out) {
   HIP_TRY(c, hipEventCreate(&c->evm0));
   HIP_TRY(c, hipEventCreate(&c->evm1));
   HIP_TRY(c, hipEventCreateWithFlags(&c->evb, hipEventDisableTiming));
+  HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
   HIP_TRY(c, hipHostMalloc((void **)&c->h_bounds, 64, hipHostMallocDefault));
   { int rc = upload_exp_table(c); if (rc) return rc; }
   {
@@ -254,7 +260,9 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->evm1) e = hipEventDestroy(c->evm1);
   if (c->evb) e = hipEventDestroy(c->evb);
   if (c->h_bounds) e = hipHostFree(c->h_bounds);
-  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_ws, c->d_pf, c->d_rn};
+  if (c->ev_mm) e = hipEventDestroy(c->ev_mm);
+  if (c->h_mm) e = hipHostFree(c->h_mm);
+  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
   delete c;
@@ -818,6 +826,236 @@ int ndt_remove_neighbors(ndt_ctx *ctx, const float *base_xy_host, size_t base_st
   HIP_TRY(ctx, hipStreamSynchronize(st));
   *n_out = (size_t)cnt;
   HIP_TRY(ctx, hipMemcpyAsync(out_xy_host, d_out, (size_t)cnt * sizeof(float2), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return NDT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+// Local-map assembly: the job table and the piece table are written into pinned memory, uploaded with one
+// copy and consumed by the kernels of ndt_localmap.hip.h.  Device scratch (ctx->d_mm):
+// [jobs][pieces][piece offsets][counts 2 x jobs][voxel sets][diff lists][kept lists].
+struct MmPlan {
+  struct Pair { const float *a0, *a1, *b; size_t n0, n1, nb; };
+  std::vector<Pair> pairs;
+  size_t sa = 8, sb = 8;
+  bool want_kept = true;
+  size_t piece_room = 0;
+};
+struct MmLayout {
+  size_t o_segs = 0, o_soff = 0, o_cnt = 0, o_tab = 0, o_diff = 0, o_kept = 0;
+  MmJob *jobs = nullptr;     // pinned, valid until the next call on this context
+  MmSeg *segs = nullptr;     // pinned
+};
+
+size_t pow2_at_least(size_t v) { size_t c = 64; while (c < v) c <<= 1; return c; }
+size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+int mm_prepare(ndt_ctx *ctx, const MmPlan &P, float2 *diff_override, hipStream_t st, MmLayout *Lo) {
+  const size_t nj = P.pairs.size();
+  size_t tab_words = 0, list_pts = 0;
+  for (const auto &q : P.pairs) { tab_words += pow2_at_least(2 * (q.n0 + q.n1) + 2); list_pts += q.nb; }
+  MmLayout L;
+  L.o_segs = up64(nj * sizeof(MmJob));
+  L.o_soff = L.o_segs + up64(P.piece_room * sizeof(MmSeg));
+  L.o_cnt = L.o_soff + up64(P.piece_room * 8);
+  L.o_tab = L.o_cnt + up64(2 * nj * 8 + 8);
+  L.o_diff = L.o_tab + tab_words * 8;
+  L.o_kept = L.o_diff + up64(list_pts * 8);
+  const size_t total = L.o_kept + list_pts * 8 + 64;
+  int rc;
+  if ((rc = ensure(ctx, &ctx->d_mm, &ctx->d_mm_cap, total))) return rc;
+  if (ctx->mm_pending) { HIP_TRY(ctx, hipEventSynchronize(ctx->ev_mm)); ctx->mm_pending = false; }
+  if (L.o_soff > ctx->h_mm_cap) {
+    if (ctx->h_mm) { hipError_t e = hipHostFree(ctx->h_mm); (void)e; ctx->h_mm = nullptr; ctx->h_mm_cap = 0; }
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_mm, 2 * L.o_soff + 256, hipHostMallocDefault));
+    ctx->h_mm_cap = 2 * L.o_soff + 256;
+  }
+  char *d = (char *)ctx->d_mm, *h = (char *)ctx->h_mm;
+  L.jobs = (MmJob *)h;
+  L.segs = (MmSeg *)(h + L.o_segs);
+  unsigned long long *d_cnt = (unsigned long long *)(d + L.o_cnt);
+  size_t tw = 0, lp = 0;
+  for (size_t j = 0; j < nj; ++j) {
+    const auto &q = P.pairs[j];
+    const size_t cap = pow2_at_least(2 * (q.n0 + q.n1) + 2);
+    MmJob &J = L.jobs[j];
+    J.a0 = q.a0; J.a1 = q.a1; J.b = q.b;
+    J.n0 = (unsigned)q.n0; J.n1 = (unsigned)q.n1; J.nb = (unsigned)q.nb;
+    J.sa = (unsigned)P.sa; J.sb = (unsigned)P.sb;
+    J.tab_mask = (unsigned)(cap - 1);
+    J.tab = (unsigned long long *)(d + L.o_tab) + tw;
+    J.diff = diff_override ? diff_override : (float2 *)(d + L.o_diff) + lp;
+    J.kept = P.want_kept ? (float2 *)(d + L.o_kept) + lp : nullptr;
+    J.n_diff = d_cnt + 2 * j;
+    J.n_kept = P.want_kept ? d_cnt + 2 * j + 1 : nullptr;
+    tw += cap; lp += q.nb;
+  }
+  if (tab_words) HIP_TRY(ctx, hipMemsetAsync(d + L.o_tab, 0xff, tab_words * 8, st));
+  *Lo = L;
+  return NDT_OK;
+}
+
+// uploads jobs + pieces and queues the kernels; out/n_out are only used when there are pieces
+int mm_run(ndt_ctx *ctx, const MmLayout &L, size_t nj, size_t nseg, size_t max_piece, double resol, double thre,
+           float *out_xy, uint64_t *n_out, hipStream_t st) {
+  char *d = (char *)ctx->d_mm;
+  const size_t bytes = nseg ? L.o_segs + nseg * sizeof(MmSeg) : nj * sizeof(MmJob);
+  if (bytes) {
+    HIP_TRY(ctx, hipMemcpyAsync(d, ctx->h_mm, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_mm, st));
+    ctx->mm_pending = true;
+  }
+  if (nj) make_map_triple_kernel<<<(unsigned)nj, kMmBlock, 0, st>>>((const MmJob *)d, resol, thre);
+  if (nseg) {
+    const MmSeg *segs = (const MmSeg *)(d + L.o_segs);
+    unsigned long long *soff = (unsigned long long *)(d + L.o_soff);
+    make_map_offsets_kernel<<<1, 64, 0, st>>>(segs, (int)nseg, soff, (unsigned long long *)n_out);
+    unsigned gx = (unsigned)((max_piece + 255) / 256);
+    if (gx < 1) gx = 1;
+    if (gx > 64) gx = 64;
+    make_map_copy_kernel<<<dim3(gx, (unsigned)nseg), 256, 0, st>>>(segs, soff, (float2 *)out_xy);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return NDT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ndt_difference_extraction_dev(ndt_ctx *ctx, const float *base_xy, size_t base_stride, size_t n_base,
+                                  const float *test_xy, size_t test_stride, size_t n_test, double resol, float *out_xy,
+                                  uint64_t *n_out, void *stream) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if ((n_base && !base_xy) || !test_xy || n_test == 0 || n_base + n_test > (size_t)(1u << 30) || !out_xy || !n_out ||
+      base_stride < 8 || (base_stride & 7) || test_stride < 8 || (test_stride & 7) || !(resol > 0.0) || !std::isfinite(resol))
+    return fail(ctx, NDT_E_ARG, "ndt_difference_extraction: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  MmPlan P;
+  P.pairs.push_back({base_xy, base_xy, test_xy, n_base, 0, n_test});
+  P.sa = base_stride; P.sb = test_stride; P.want_kept = false;
+  MmLayout L;
+  int rc;
+  // the difference list is written straight to the caller's buffer, its count to the caller's counter
+  if ((rc = mm_prepare(ctx, P, (float2 *)out_xy, st, &L))) return rc;
+  L.jobs[0].n_diff = (unsigned long long *)n_out;
+  return mm_run(ctx, L, 1, 0, 0, resol, 0.0, nullptr, nullptr, st);
+}
+
+int ndt_difference_extraction(ndt_ctx *ctx, const float *base_xy_host, size_t base_stride, size_t n_base,
+                              const float *test_xy_host, size_t test_stride, size_t n_test, double resol,
+                              float *out_xy_host, size_t *n_out) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if ((n_base && !base_xy_host) || (n_test && !test_xy_host) || !out_xy_host || !n_out || base_stride < 8 ||
+      (base_stride & 7) || test_stride < 8 || (test_stride & 7))
+    return fail(ctx, NDT_E_ARG, "ndt_difference_extraction: bad arguments");
+  if (n_test == 0) { *n_out = 0; return NDT_OK; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  const size_t bb = (n_base * base_stride + 15) & ~(size_t)15, tb = (n_test * test_stride + 15) & ~(size_t)15;
+  if ((rc = ensure(ctx, &ctx->d_scan, &ctx->d_scan_cap, bb + tb + n_test * sizeof(float2) + 64))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_off, &ctx->d_off_cap, 4 * sizeof(uint64_t)))) return rc;
+  char *d = (char *)ctx->d_scan;
+  float *d_base = (float *)d, *d_test = (float *)(d + bb), *d_out = (float *)(d + bb + tb);
+  if (n_base) HIP_TRY(ctx, hipMemcpyAsync(d_base, base_xy_host, n_base * base_stride, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipMemcpyAsync(d_test, test_xy_host, n_test * test_stride, hipMemcpyHostToDevice, st));
+  if ((rc = ndt_difference_extraction_dev(ctx, d_base, base_stride, n_base, d_test, test_stride, n_test, resol, d_out,
+                                          (uint64_t *)ctx->d_off, st)))
+    return rc;
+  uint64_t cnt = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&cnt, ctx->d_off, sizeof(cnt), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (cnt == ~0ull) return fail(ctx, NDT_E_ARG, "ndt_difference_extraction: the clouds span more than 2^30 voxels");
+  *n_out = (size_t)cnt;
+  if (cnt) HIP_TRY(ctx, hipMemcpyAsync(out_xy_host, d_out, (size_t)cnt * sizeof(float2), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return NDT_OK;
+}
+
+int ndt_make_map_dev(ndt_ctx *ctx, const float *scans_xy, size_t stride, const uint64_t *offsets, int n_scans,
+                     int first_submap, int newest, int remove_moving, double resol, double thre_neighbor, float *out_xy,
+                     uint64_t *n_out, void *stream) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!scans_xy || !offsets || n_scans <= 0 || n_scans > (1 << 20) || !out_xy || !n_out || stride < 8 || (stride & 7) ||
+      (remove_moving && (!(resol > 0.0) || !std::isfinite(resol) || !std::isfinite(thre_neighbor))))
+    return fail(ctx, NDT_E_ARG, "ndt_make_map: bad arguments");
+  for (int i = 0; i < n_scans; ++i)
+    if (offsets[i + 1] < offsets[i] || offsets[i + 1] - offsets[i] > (uint64_t)(1u << 29))
+      return fail(ctx, NDT_E_ARG, "ndt_make_map: offsets must be non-decreasing, scans below 2^29 points");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  auto scan_ptr = [&](int i) { return (const float *)((const char *)scans_xy + (size_t)offsets[i] * stride); };
+  auto scan_n = [&](int i) { return (size_t)(offsets[i + 1] - offsets[i]); };
+  MmPlan P;
+  P.sa = P.sb = stride;
+  if (remove_moving)
+    for (int i = 0; i + 2 < n_scans; ++i)
+      if (scan_n(i + 1))     // an empty middle scan contributes nothing
+        P.pairs.push_back({scan_ptr(i), scan_ptr(i + 2), scan_ptr(i + 1), scan_n(i), scan_n(i + 2), scan_n(i + 1)});
+  P.piece_room = (size_t)n_scans + 2;
+  MmLayout L;
+  int rc;
+  if ((rc = mm_prepare(ctx, P, nullptr, st, &L))) return rc;
+  MmSeg *hs = L.segs; const MmJob *hj = L.jobs;
+  // the pieces of p_cloud in the order Submap::makeMap appends them
+  size_t nseg = 0, max_piece = 0;
+  auto whole = [&](int i) {
+    if (!scan_n(i)) return;
+    hs[nseg++] = MmSeg{scan_ptr(i), (unsigned)stride, (unsigned)scan_n(i), nullptr};
+    if (scan_n(i) > max_piece) max_piece = scan_n(i);
+  };
+  if (remove_moving) {
+    if (first_submap) whole(0);
+    for (size_t j = 0; j < P.pairs.size(); ++j) {
+      hs[nseg++] = MmSeg{(const float *)hj[j].kept, 8u, hj[j].nb, hj[j].n_kept};
+      if (hj[j].nb > max_piece) max_piece = hj[j].nb;
+    }
+    if (newest) whole(n_scans - 1);
+  } else {
+    for (int i = first_submap ? 0 : 2; i < n_scans; ++i) whole(i);
+  }
+  if (nseg == 0) {
+    HIP_TRY(ctx, hipMemsetAsync(n_out, 0, sizeof(uint64_t), st));
+    return mm_run(ctx, L, P.pairs.size(), 0, 0, resol, thre_neighbor, nullptr, nullptr, st);
+  }
+  return mm_run(ctx, L, P.pairs.size(), nseg, max_piece, resol, thre_neighbor, out_xy, n_out, st);
+}
+
+int ndt_make_map(ndt_ctx *ctx, const float *scans_xy_host, size_t stride, const uint64_t *offsets, int n_scans,
+                 int first_submap, int newest, int remove_moving, double resol, double thre_neighbor,
+                 float *out_xy_host, size_t *n_out) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!scans_xy_host || !offsets || n_scans <= 0 || !out_xy_host || !n_out || stride < 8 || (stride & 7))
+    return fail(ctx, NDT_E_ARG, "ndt_make_map: bad arguments");
+  const size_t total = (size_t)offsets[n_scans] - (size_t)offsets[0];
+  if (total == 0) { *n_out = 0; return NDT_OK; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  int rc;
+  const size_t ib = (total * stride + 15) & ~(size_t)15;
+  const size_t out_pts = n_scans == 1 ? 2 * total : total;      // a lone scan is appended twice (first + newest)
+  if ((rc = ensure(ctx, &ctx->d_scan, &ctx->d_scan_cap, ib + out_pts * sizeof(float2) + 64))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_off, &ctx->d_off_cap, 4 * sizeof(uint64_t)))) return rc;
+  char *d = (char *)ctx->d_scan;
+  float *d_in = (float *)d, *d_out = (float *)(d + ib);
+  HIP_TRY(ctx, hipMemcpyAsync(d_in, (const char *)scans_xy_host + (size_t)offsets[0] * stride, total * stride,
+                              hipMemcpyHostToDevice, st));
+  std::vector<uint64_t> rel((size_t)n_scans + 1);
+  for (int i = 0; i <= n_scans; ++i) rel[i] = offsets[i] - offsets[0];
+  if ((rc = ndt_make_map_dev(ctx, d_in, stride, rel.data(), n_scans, first_submap, newest, remove_moving, resol,
+                             thre_neighbor, d_out, (uint64_t *)ctx->d_off, st)))
+    return rc;
+  uint64_t cnt = 0;
+  HIP_TRY(ctx, hipMemcpyAsync(&cnt, ctx->d_off, sizeof(cnt), hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  if (cnt == ~0ull) return fail(ctx, NDT_E_ARG, "ndt_make_map: a scan triple spans more than 2^30 voxels");
+  *n_out = (size_t)cnt;
+  if (cnt) HIP_TRY(ctx, hipMemcpyAsync(out_xy_host, d_out, (size_t)cnt * sizeof(float2), hipMemcpyDeviceToHost, st));
   HIP_TRY(ctx, hipStreamSynchronize(st));
   return NDT_OK;
 }

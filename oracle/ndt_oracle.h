@@ -168,6 +168,17 @@ int ndt_oracle_fuse(const ndt_oracle_result *r, const double pred[3], const doub
 size_t ndt_oracle_remove_neighbors(const float *base_xy, size_t n_base, const float *list_xy, size_t n_list,
                                    double thre_neighbor, float *out_xy);
 
+/* SURVEY.md 8f row f3 (rest), oracle/ndt_oracle_octree.c: PCFilter::difference_extraction
+ * (include/ndt_slam/PCFilter.h:58-94) on a literal two-buffer pointer octree restated from PCL's published
+ * OctreePointCloudChangeDetector, and Submap::makeMap (src/PointCloudMap.cpp:15-39) on top of it.
+ * Both return (size_t)-1 when the clouds span more than 2^30 voxels of `resol`. */
+size_t ndt_oracle_difference_indices(const float *base_xy, size_t n_base, const float *test_xy, size_t n_test,
+                                     double resol, int *out_idx);
+size_t ndt_oracle_difference_extraction(const float *base_xy, size_t n_base, const float *test_xy, size_t n_test,
+                                        double resol, float *out_xy);
+size_t ndt_oracle_make_map(const float *scans_xy, const size_t *offsets, int n_scans, int first_submap, int newest,
+                           int remove_moving, double resol, double thre_neighbor, float *out_xy);
+
 #ifdef __cplusplus
 }
 #endif

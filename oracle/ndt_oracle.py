@@ -50,9 +50,8 @@ assert RESULT_DTYPE.itemsize == C.sizeof(Result)
 
 def build(force=False):
     so = os.path.join(_HERE, "libndt_oracle.so")
-    src = os.path.join(_HERE, "ndt_oracle.c")
-    hdr = os.path.join(_HERE, "ndt_oracle.h")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+    deps = [os.path.join(_HERE, f) for f in ("ndt_oracle.c", "ndt_oracle_octree.c", "ndt_oracle.h", "Makefile")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libndt_oracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -246,4 +245,41 @@ def remove_neighbors(base, point_list, thre_neighbor):
     L.ndt_oracle_remove_neighbors.restype = C.c_size_t
     L.ndt_oracle_remove_neighbors.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]
     n = L.ndt_oracle_remove_neighbors(base.ctypes.data, len(base), lst.ctypes.data, len(lst), thre_neighbor, out.ctypes.data)
+    return out[:n].copy()
+
+
+def difference_indices(base, test, resol):
+    """PCFilter::difference_extraction on the literal octree: indices into `test`, in the detector's order."""
+    base = np.ascontiguousarray(base, dtype=np.float32).reshape(-1, 2)
+    test = np.ascontiguousarray(test, dtype=np.float32).reshape(-1, 2)
+    idx = np.zeros(len(test) + 1, dtype=np.int32)
+    L = lib()
+    L.ndt_oracle_difference_indices.restype = C.c_size_t
+    L.ndt_oracle_difference_indices.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_double, C.c_void_p]
+    n = L.ndt_oracle_difference_indices(base.ctypes.data, len(base), test.ctypes.data, len(test), resol, idx.ctypes.data)
+    if n == C.c_size_t(-1).value:
+        raise ValueError("clouds span more than 2^30 voxels")
+    return idx[:n].copy()
+
+
+def difference_extraction(base, test, resol):
+    test = np.ascontiguousarray(test, dtype=np.float32).reshape(-1, 2)
+    return test[difference_indices(base, test, resol)]
+
+
+def make_map(scans, first_submap, newest, remove_moving, resol, thre_neighbor):
+    """Submap::makeMap over a list of (n_i, 2) float32 scans -> (n, 2) float32 local-map points."""
+    scans = [np.ascontiguousarray(s, dtype=np.float32).reshape(-1, 2) for s in scans]
+    off = np.zeros(len(scans) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(s) for s in scans])
+    allp = np.concatenate(scans) if scans else np.zeros((0, 2), np.float32)
+    out = np.zeros(((2 if len(scans) == 1 else 1) * len(allp) + 1, 2), dtype=np.float32)   # one scan: appended twice
+    L = lib()
+    L.ndt_oracle_make_map.restype = C.c_size_t
+    L.ndt_oracle_make_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                      C.c_void_p]
+    n = L.ndt_oracle_make_map(allp.ctypes.data, off.ctypes.data, len(scans), int(first_submap), int(newest),
+                              int(remove_moving), resol, thre_neighbor, out.ctypes.data)
+    if n == C.c_size_t(-1).value:
+        raise ValueError("clouds span more than 2^30 voxels")
     return out[:n].copy()
