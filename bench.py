@@ -279,6 +279,38 @@ def main():
                                  "scans": B, "raw_points_per_scan": int(len(raw) // B), "ms": float(np.median(ts)),
                                  "scans_per_s": B / (float(np.median(ts)) * 1e-3), "accepted": int(d_ok.sum().item())}
 
+    # Row f3 (local-map assembly, Submap::makeMap with moving-object removal): a submap of 12 registered scans
+    # of the metric's size (walls seen again by every scan + an object that moves, synth.submap_scans) assembled
+    # on the device; the oracle's literal octree does the same on one host core (checker and CPU figure).
+    # Reported beside the headline metric, not part of it.
+    if rank == 0 and world == 1 and not args.no_single_scan:
+        ns = 12
+        reg = synth.submap_scans(ns, cfg["n_scan"])
+        reg_off = np.zeros(ns + 1, np.uint64)
+        reg_off[1:] = np.cumsum([len(r) for r in reg])
+        d_reg = torch.from_numpy(np.concatenate(reg)).to(dev)
+        d_lm = torch.empty((len(d_reg) + 1, 2), dtype=torch.float32, device=dev)
+        d_cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ts = []
+        for _ in range(6):
+            e0.record(stream)
+            ctx.make_map_dev(d_reg.data_ptr(), 8, reg_off, True, True, True, 0.05, 0.1, d_lm.data_ptr(), d_cnt.data_ptr(),
+                             stream=stream.cuda_stream)
+            e1.record(stream)
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        n_lm = int(d_cnt.item())
+        lm = {"scans": ns, "points": int(len(d_reg)), "kept": n_lm, "resol": 0.05, "thre_neighbor": 0.1,
+              "ms": float(np.median(ts[1:]))}
+        if not args.no_cpu_baseline:
+            from oracle import ndt_oracle as O
+            t = time.perf_counter()
+            ref_lm = O.make_map(reg, True, True, True, 0.05, 0.1)
+            lm["cpu_ms_1core"] = (time.perf_counter() - t) * 1e3
+            lm["identical"] = bool(n_lm == len(ref_lm) and d_lm[:n_lm].cpu().numpy().tobytes() == ref_lm.tobytes())
+        out["local_map"] = lm
+
     # CPU baseline: the oracle (a port -- PCL itself is absent) on this box's host cores,
     # rank 0 at N = 1 only, on a bounded sample of the same batch.
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

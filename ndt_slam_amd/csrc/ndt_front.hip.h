@@ -423,18 +423,33 @@ fuse_kernel(const ndt_result *__restrict__ res, const double *__restrict__ pred_
 // reference tests every pair (O(n*m) on the CPU, the largest cost outside NDT when moving
 // objects are removed, src/PointCloudMap.cpp:15-39); here one lane per base point walks the list
 // through LDS tiles.  The distance is PCLUtil::distance_points' float32 expression
-// (include/ndt_slam/PCLUtil.h:21-23) compared with the double threshold, so the kept set is
-// identical; a ballot prefix keeps the order.
+// (include/ndt_slam/PCLUtil.h:21-23) compared with the double threshold (through rn_cutoff), so the
+// kept set is identical; a ballot prefix keeps the order.
 // ------------------------------------------------------------------------------------------
 constexpr int kRnBlock = 256, kRnTile = 1024;
-__device__ __forceinline__ bool rn_near(float2 p, float2 q, double thre) {
+// The reference's test is (double)sqrtf(d2) < thre with d2 the float32 squared distance.  sqrtf is correctly
+// rounded and monotone, so the test equals d2 < cut with cut the smallest float whose square root reaches
+// thre; rn_cutoff finds it on the host (bisection over the float bit patterns), and the device needs no sqrt.
+inline float rn_cutoff(double thre) {
+  if (!(thre > 0.0)) return 0.0f;                                   // nothing is closer than a non-positive bound
+  if (!((double)sqrtf(FLT_MAX) >= thre)) return INFINITY;           // every finite distance is
+  unsigned lo = 0u, hi = 0x7f7fffffu;                               // float bits: (double)sqrtf(hi) >= thre holds
+  while (lo < hi) {
+    const unsigned mid = lo + (hi - lo) / 2;
+    float f; memcpy(&f, &mid, 4);
+    if ((double)sqrtf(f) >= thre) hi = mid; else lo = mid + 1;
+  }
+  float f; memcpy(&f, &lo, 4);
+  return f;
+}
+__device__ __forceinline__ bool rn_near(float2 p, float2 q, float cut) {
   const float dx = p.x - q.x, dy = p.y - q.y;
   const float d2 = dx * dx + dy * dy;            // (+ dz*dz with dz = 0 adds nothing)
-  return (double)sqrtf(d2) < thre;
+  return d2 < cut;
 }
 __global__ void __launch_bounds__(kRnBlock)
 remove_neighbors_flag_kernel(const float *__restrict__ base, size_t bstride, int nb, const float *__restrict__ list,
-                             size_t lstride, int nl, double thre, unsigned char *__restrict__ keep,
+                             size_t lstride, int nl, float cut, unsigned char *__restrict__ keep,
                              int *__restrict__ block_count) {
   __shared__ float2 tile[kRnTile];
   __shared__ int wsum[kRnBlock / 64];
@@ -449,7 +464,7 @@ remove_neighbors_flag_kernel(const float *__restrict__ base, size_t bstride, int
     __syncthreads();
     if (flag) {                                   // (the reference keeps testing; the outcome is the same)
       bool near = false;
-      for (int j = 0; j < m; ++j) near = near || rn_near(p, tile[j], thre);
+      for (int j = 0; j < m; ++j) near = near || rn_near(p, tile[j], cut);
       flag = !near;
     }
   }

@@ -17,6 +17,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -24,6 +25,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "ndt_mi355x.h"
@@ -794,7 +796,7 @@ int ndt_remove_neighbors_dev(ndt_ctx *ctx, const float *base_xy, size_t base_str
   int *block_count = (int *)ctx->d_rn;
   unsigned char *keep = (unsigned char *)ctx->d_rn + (size_t)nblocks * sizeof(int);
   remove_neighbors_flag_kernel<<<nblocks, kRnBlock, 0, st>>>(base_xy, base_stride, (int)n_base, list_xy, list_stride,
-                                                             (int)n_list, thre_neighbor, keep, block_count);
+                                                             (int)n_list, rn_cutoff(thre_neighbor), keep, block_count);
   remove_neighbors_scan_kernel<<<1, 1024, 0, st>>>(block_count, nblocks, (unsigned long long *)n_out);
   remove_neighbors_pack_kernel<<<nblocks, kRnBlock, 0, st>>>(base_xy, base_stride, (int)n_base, keep, block_count,
                                                              (float2 *)out_xy);
@@ -834,48 +836,49 @@ int ndt_remove_neighbors(ndt_ctx *ctx, const float *base_xy_host, size_t base_st
 
 namespace {
 
-// Local-map assembly: the job table and the piece table are written into pinned memory, uploaded with one
-// copy and consumed by the kernels of ndt_localmap.hip.h.  Device scratch (ctx->d_mm):
-// [jobs][pieces][piece offsets][counts 2 x jobs][voxel sets][diff lists][kept lists].
+// Local-map assembly: the job table (one entry per scan triple) and the unit table (256-point stretches of the
+// result) are written into pinned memory, uploaded with one copy and consumed by the kernels of
+// ndt_localmap.hip.h.  Device scratch (ctx->d_mm):
+// [jobs][units][unit counts][unit offsets][keep bits][diff counts][voxel sets][diff lists].
 struct MmPlan {
   struct Pair { const float *a0, *a1, *b; size_t n0, n1, nb; };
   std::vector<Pair> pairs;
   size_t sa = 8, sb = 8;
-  bool want_kept = true;
-  size_t piece_room = 0;
+  size_t unit_room = 0;
 };
 struct MmLayout {
-  size_t o_segs = 0, o_soff = 0, o_cnt = 0, o_tab = 0, o_diff = 0, o_kept = 0;
+  size_t o_units = 0, o_ucnt = 0, o_uoff = 0, o_keep = 0, o_cnt = 0, o_tab = 0, o_diff = 0;
   MmJob *jobs = nullptr;     // pinned, valid until the next call on this context
-  MmSeg *segs = nullptr;     // pinned
+  MmUnit *units = nullptr;   // pinned
 };
 
 size_t pow2_at_least(size_t v) { size_t c = 64; while (c < v) c <<= 1; return c; }
 size_t up64(size_t v) { return (v + 63) & ~(size_t)63; }
 
 int mm_prepare(ndt_ctx *ctx, const MmPlan &P, float2 *diff_override, hipStream_t st, MmLayout *Lo) {
-  const size_t nj = P.pairs.size();
+  const size_t nj = P.pairs.size(), nu = P.unit_room;
   size_t tab_words = 0, list_pts = 0;
   for (const auto &q : P.pairs) { tab_words += pow2_at_least(2 * (q.n0 + q.n1) + 2); list_pts += q.nb; }
   MmLayout L;
-  L.o_segs = up64(nj * sizeof(MmJob));
-  L.o_soff = L.o_segs + up64(P.piece_room * sizeof(MmSeg));
-  L.o_cnt = L.o_soff + up64(P.piece_room * 8);
-  L.o_tab = L.o_cnt + up64(2 * nj * 8 + 8);
+  L.o_units = up64(nj * sizeof(MmJob));
+  L.o_ucnt = L.o_units + up64(nu * sizeof(MmUnit));
+  L.o_uoff = L.o_ucnt + up64(nu * 4);
+  L.o_keep = L.o_uoff + up64(nu * 8);
+  L.o_cnt = L.o_keep + up64(nu * (kMmUnit / 64) * 8);
+  L.o_tab = L.o_cnt + up64(nj * 8 + 8);
   L.o_diff = L.o_tab + tab_words * 8;
-  L.o_kept = L.o_diff + up64(list_pts * 8);
-  const size_t total = L.o_kept + list_pts * 8 + 64;
+  const size_t total = L.o_diff + list_pts * 8 + 64;
   int rc;
   if ((rc = ensure(ctx, &ctx->d_mm, &ctx->d_mm_cap, total))) return rc;
   if (ctx->mm_pending) { HIP_TRY(ctx, hipEventSynchronize(ctx->ev_mm)); ctx->mm_pending = false; }
-  if (L.o_soff > ctx->h_mm_cap) {
+  if (L.o_ucnt > ctx->h_mm_cap) {
     if (ctx->h_mm) { hipError_t e = hipHostFree(ctx->h_mm); (void)e; ctx->h_mm = nullptr; ctx->h_mm_cap = 0; }
-    HIP_TRY(ctx, hipHostMalloc(&ctx->h_mm, 2 * L.o_soff + 256, hipHostMallocDefault));
-    ctx->h_mm_cap = 2 * L.o_soff + 256;
+    HIP_TRY(ctx, hipHostMalloc(&ctx->h_mm, 2 * L.o_ucnt + 256, hipHostMallocDefault));
+    ctx->h_mm_cap = 2 * L.o_ucnt + 256;
   }
   char *d = (char *)ctx->d_mm, *h = (char *)ctx->h_mm;
   L.jobs = (MmJob *)h;
-  L.segs = (MmSeg *)(h + L.o_segs);
+  L.units = (MmUnit *)(h + L.o_units);
   unsigned long long *d_cnt = (unsigned long long *)(d + L.o_cnt);
   size_t tw = 0, lp = 0;
   for (size_t j = 0; j < nj; ++j) {
@@ -888,9 +891,7 @@ int mm_prepare(ndt_ctx *ctx, const MmPlan &P, float2 *diff_override, hipStream_t
     J.tab_mask = (unsigned)(cap - 1);
     J.tab = (unsigned long long *)(d + L.o_tab) + tw;
     J.diff = diff_override ? diff_override : (float2 *)(d + L.o_diff) + lp;
-    J.kept = P.want_kept ? (float2 *)(d + L.o_kept) + lp : nullptr;
-    J.n_diff = d_cnt + 2 * j;
-    J.n_kept = P.want_kept ? d_cnt + 2 * j + 1 : nullptr;
+    J.n_diff = d_cnt + j;
     tw += cap; lp += q.nb;
   }
   if (tab_words) HIP_TRY(ctx, hipMemsetAsync(d + L.o_tab, 0xff, tab_words * 8, st));
@@ -898,25 +899,25 @@ int mm_prepare(ndt_ctx *ctx, const MmPlan &P, float2 *diff_override, hipStream_t
   return NDT_OK;
 }
 
-// uploads jobs + pieces and queues the kernels; out/n_out are only used when there are pieces
-int mm_run(ndt_ctx *ctx, const MmLayout &L, size_t nj, size_t nseg, size_t max_piece, double resol, double thre,
-           float *out_xy, uint64_t *n_out, hipStream_t st) {
+// uploads jobs + units and queues the kernels; out/n_out are only used when there are units
+int mm_run(ndt_ctx *ctx, const MmLayout &L, size_t nj, size_t nu, double resol, double thre, float *out_xy,
+           uint64_t *n_out, hipStream_t st) {
   char *d = (char *)ctx->d_mm;
-  const size_t bytes = nseg ? L.o_segs + nseg * sizeof(MmSeg) : nj * sizeof(MmJob);
+  const size_t bytes = nu ? L.o_units + nu * sizeof(MmUnit) : nj * sizeof(MmJob);
   if (bytes) {
     HIP_TRY(ctx, hipMemcpyAsync(d, ctx->h_mm, bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipEventRecord(ctx->ev_mm, st));
     ctx->mm_pending = true;
   }
-  if (nj) make_map_triple_kernel<<<(unsigned)nj, kMmBlock, 0, st>>>((const MmJob *)d, resol, thre);
-  if (nseg) {
-    const MmSeg *segs = (const MmSeg *)(d + L.o_segs);
-    unsigned long long *soff = (unsigned long long *)(d + L.o_soff);
-    make_map_offsets_kernel<<<1, 64, 0, st>>>(segs, (int)nseg, soff, (unsigned long long *)n_out);
-    unsigned gx = (unsigned)((max_piece + 255) / 256);
-    if (gx < 1) gx = 1;
-    if (gx > 64) gx = 64;
-    make_map_copy_kernel<<<dim3(gx, (unsigned)nseg), 256, 0, st>>>(segs, soff, (float2 *)out_xy);
+  if (nj) make_map_diff_kernel<<<(unsigned)nj, kMmBlock, 0, st>>>((const MmJob *)d, resol);
+  if (nu) {
+    const MmUnit *units = (const MmUnit *)(d + L.o_units);
+    unsigned *ucnt = (unsigned *)(d + L.o_ucnt);
+    unsigned long long *uoff = (unsigned long long *)(d + L.o_uoff), *keep = (unsigned long long *)(d + L.o_keep);
+    make_map_flag_kernel<<<(unsigned)nu, kMmUnit, 0, st>>>((const MmJob *)d, units, rn_cutoff(thre), keep, ucnt);
+    make_map_offsets_kernel<<<1, 1024, 0, st>>>(ucnt, (int)nu, uoff, (unsigned long long *)n_out);
+    make_map_copy_kernel<<<(unsigned)nu, kMmUnit, 0, st>>>(units, keep, uoff, (const unsigned long long *)n_out,
+                                                          (float2 *)out_xy);
   }
   HIP_TRY(ctx, hipGetLastError());
   return NDT_OK;
@@ -937,13 +938,13 @@ int ndt_difference_extraction_dev(ndt_ctx *ctx, const float *base_xy, size_t bas
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   MmPlan P;
   P.pairs.push_back({base_xy, base_xy, test_xy, n_base, 0, n_test});
-  P.sa = base_stride; P.sb = test_stride; P.want_kept = false;
+  P.sa = base_stride; P.sb = test_stride;
   MmLayout L;
   int rc;
   // the difference list is written straight to the caller's buffer, its count to the caller's counter
   if ((rc = mm_prepare(ctx, P, (float2 *)out_xy, st, &L))) return rc;
   L.jobs[0].n_diff = (unsigned long long *)n_out;
-  return mm_run(ctx, L, 1, 0, 0, resol, 0.0, nullptr, nullptr, st);
+  return mm_run(ctx, L, 1, 0, resol, 0.0, nullptr, nullptr, st);
 }
 
 int ndt_difference_extraction(ndt_ctx *ctx, const float *base_xy_host, size_t base_stride, size_t n_base,
@@ -997,33 +998,31 @@ int ndt_make_map_dev(ndt_ctx *ctx, const float *scans_xy, size_t stride, const u
     for (int i = 0; i + 2 < n_scans; ++i)
       if (scan_n(i + 1))     // an empty middle scan contributes nothing
         P.pairs.push_back({scan_ptr(i), scan_ptr(i + 2), scan_ptr(i + 1), scan_n(i), scan_n(i + 2), scan_n(i + 1)});
-  P.piece_room = (size_t)n_scans + 2;
+  // the pieces of p_cloud in the order Submap::makeMap appends them: (scan, triple or -1)
+  std::vector<std::pair<int, int>> pieces;
+  if (remove_moving) {
+    if (first_submap) pieces.push_back({0, -1});
+    int j = 0;
+    for (int i = 0; i + 2 < n_scans; ++i) if (scan_n(i + 1)) pieces.push_back({i + 1, j++});
+    if (newest) pieces.push_back({n_scans - 1, -1});
+  } else {
+    for (int i = first_submap ? 0 : 2; i < n_scans; ++i) pieces.push_back({i, -1});
+  }
+  size_t nu = 0;
+  for (const auto &pc : pieces) nu += (scan_n(pc.first) + kMmUnit - 1) / kMmUnit;
+  P.unit_room = nu;
   MmLayout L;
   int rc;
   if ((rc = mm_prepare(ctx, P, nullptr, st, &L))) return rc;
-  MmSeg *hs = L.segs; const MmJob *hj = L.jobs;
-  // the pieces of p_cloud in the order Submap::makeMap appends them
-  size_t nseg = 0, max_piece = 0;
-  auto whole = [&](int i) {
-    if (!scan_n(i)) return;
-    hs[nseg++] = MmSeg{scan_ptr(i), (unsigned)stride, (unsigned)scan_n(i), nullptr};
-    if (scan_n(i) > max_piece) max_piece = scan_n(i);
-  };
-  if (remove_moving) {
-    if (first_submap) whole(0);
-    for (size_t j = 0; j < P.pairs.size(); ++j) {
-      hs[nseg++] = MmSeg{(const float *)hj[j].kept, 8u, hj[j].nb, hj[j].n_kept};
-      if (hj[j].nb > max_piece) max_piece = hj[j].nb;
-    }
-    if (newest) whole(n_scans - 1);
-  } else {
-    for (int i = first_submap ? 0 : 2; i < n_scans; ++i) whole(i);
+  size_t u = 0;
+  for (const auto &pc : pieces) {
+    const size_t n = scan_n(pc.first);
+    for (size_t o = 0; o < n; o += kMmUnit)
+      L.units[u++] = MmUnit{(const float *)((const char *)scan_ptr(pc.first) + o * stride), (unsigned)stride,
+                            (unsigned)std::min<size_t>(kMmUnit, n - o), pc.second, 0u};
   }
-  if (nseg == 0) {
-    HIP_TRY(ctx, hipMemsetAsync(n_out, 0, sizeof(uint64_t), st));
-    return mm_run(ctx, L, P.pairs.size(), 0, 0, resol, thre_neighbor, nullptr, nullptr, st);
-  }
-  return mm_run(ctx, L, P.pairs.size(), nseg, max_piece, resol, thre_neighbor, out_xy, n_out, st);
+  if (nu == 0) HIP_TRY(ctx, hipMemsetAsync(n_out, 0, sizeof(uint64_t), st));
+  return mm_run(ctx, L, P.pairs.size(), nu, resol, thre_neighbor, out_xy, n_out, st);
 }
 
 int ndt_make_map(ndt_ctx *ctx, const float *scans_xy_host, size_t stride, const uint64_t *offsets, int n_scans,

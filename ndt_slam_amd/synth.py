@@ -124,3 +124,21 @@ def hypothesis_seeds(truth, count=4096, seed=5, pitch=0.1, yaw_deg=10.0):
     out[:, 1] = truth[1] + gy.ravel()
     out[:, 2] = truth[2] + np.radians(rng.uniform(-yaw_deg, yaw_deg, size=count))
     return out
+
+
+def submap_scans(n_scans, n_points, seed=21, mover_frac=0.025, jitter=0.003, room=(8.0, 6.0)):
+    """Scans of one submap already registered in the map frame (input of Submap::makeMap, SURVEY.md 8f row f3):
+    the walls of a room re-observed by every scan at the same bearings with `jitter` metres of noise, plus a
+    small object that moves 0.6 m between scans (what the moving-object removal is there to drop)."""
+    rng = _rng(seed)
+    n_mover = max(1, int(n_points * mover_frac))
+    n_wall = n_points - n_mover
+    th = np.linspace(0.0, 2.0 * np.pi, n_wall, endpoint=False)
+    d = np.maximum(np.abs(np.cos(th)), np.abs(np.sin(th)))
+    walls = np.stack([room[0] * np.cos(th) / d, room[1] * np.sin(th) / d], axis=1)
+    out = []
+    for k in range(n_scans):
+        mover = np.stack([rng.normal(-3.0 + 0.6 * k, 0.1, n_mover), rng.normal(0.5, 0.15, n_mover)], axis=1)
+        out.append((np.concatenate([walls, mover]) + rng.normal(size=(n_points, 2)) * jitter).astype(np.float32))
+    return out
+

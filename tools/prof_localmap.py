@@ -8,26 +8,14 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from ndt_slam_amd import capi                      # noqa: E402
+from ndt_slam_amd import capi, synth               # noqa: E402
 from oracle import ndt_oracle as O                 # noqa: E402  (checker only)
-
-
-def scans_of(rng, n_scans, n_wall, n_mover):
-    th = np.linspace(0, 2 * np.pi, n_wall, endpoint=False)
-    d = np.maximum(abs(np.cos(th)), abs(np.sin(th)))
-    room = np.stack([8 * np.cos(th) / d, 6 * np.sin(th) / d], 1)
-    out = []
-    for k in range(n_scans):
-        mover = np.stack([rng.normal(-3 + 0.6 * k, 0.1, n_mover), rng.normal(0.5, 0.15, n_mover)], 1)
-        out.append((np.concatenate([room, mover]) + rng.normal(size=(n_wall + n_mover, 2)) * 0.003).astype(np.float32))
-    return out
 
 
 def main():
     n_scans = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     n_pts = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
-    rng = np.random.default_rng(0)
-    scans = scans_of(rng, n_scans, n_pts - n_pts // 40, n_pts // 40)
+    scans = synth.submap_scans(n_scans, n_pts)
     off = np.zeros(n_scans + 1, np.uint64)
     off[1:] = np.cumsum([len(s) for s in scans])
     ctx = capi.Context(0)

@@ -1,11 +1,11 @@
 """Copy the rocprofv3 outputs of a gpurun call into profiles/ (tracked) and derive r01_traffic.json.
-Expects gpurun_out/{r1stats,r1fetch,r1write}/run_*.csv and gpurun_out/{r1stats,r1fetch,r1write,bench_r1}.log."""
+Expects gpurun_out/{r1stats,r1fetch,r1write,r1lm}/run_*.csv and gpurun_out/{r1stats,r1fetch,r1write,bench_r1}.log."""
 import csv, json, os, shutil
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
 os.makedirs(P, exist_ok=True)
 for a, b in [("r1stats/run_kernel_stats.csv", "r01_kernel_stats.csv"), ("r1stats/run_domain_stats.csv", "r01_domain_stats.csv"),
-             ("r1stats/run_kernel_trace.csv", "r01_kernel_trace.csv")]:
+             ("r1stats/run_kernel_trace.csv", "r01_kernel_trace.csv"), ("r1lm/run_kernel_stats.csv", "r01_localmap_kernel_stats.csv")]:
     shutil.copy(os.path.join(G, a), os.path.join(P, b))
 keep = ["Dispatch_Id", "Grid_Size", "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count",
         "SGPR_Count", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]

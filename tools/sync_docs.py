@@ -21,6 +21,7 @@ s = s[:a] + f"""Round-1 numbers (1 × MI355X, `profiles/r01_bench.json`):
 | roofline | {d['roofline']['achieved']:.0f} GB/s algorithmic, frac {d['roofline']['frac']:.3f}; measured traffic {t['bytes_per_launch']/1e9:.2f} GB per launch (FETCH + WRITE, raw) |
 | source pre-filter (row f1) | 256 scans × 30k raw points in {d['prefilter']['ms']:.2f} ms ({d['prefilter']['raw_points_per_s']/1e9:.1f} G points/s) |
 | whole front-end step | predict → pre-filter → map rebuild → match → fuse for 256 raw scans of 30k points, all on the device: {d['front_end_step']['ms']:.2f} ms ({d['front_end_step']['scans_per_s']/1e3:.0f}k scans/s) |
+| local-map assembly (row f3) | `Submap::makeMap` of {d['local_map']['scans']} scans × {d['local_map']['points']//d['local_map']['scans']} points with moving-object removal: {d['local_map']['ms']:.2f} ms (oracle's pointer octree on one host core: {d['local_map']['cpu_ms_1core']:.0f} ms; identical cloud: {d['local_map']['identical']}) |
 | CPU baseline | oracle (port), 1 thread: {cb['value']:.1f} matches/s; {cb['all_cores']['cores']} threads: {cb['all_cores']['value']:.0f} matches/s |
 | parity on the bench sample | max |Δpos| = {d['parity']['max_dpos_m']} m, max |Δyaw| = {d['parity']['max_dyaw_rad']} rad, identical iteration counts ({d['parity']['sample']} scans) |
 
