@@ -142,3 +142,58 @@ def submap_scans(n_scans, n_points, seed=21, mover_frac=0.025, jitter=0.003, roo
         out.append((np.concatenate([walls, mover]) + rng.normal(size=(n_points, 2)) * jitter).astype(np.float32))
     return out
 
+
+
+def replay_records(n_frames=40, n_beams=541, fov_deg=270.0, step=0.3, seed=33, max_range=30.0, sigma=0.01,
+                   odo_scale=1.015, odo_yaw_bias_deg=0.05):
+    """Records of a synthetic drive for the replay harness (the reference's own log is not
+    in the repository): a robot circles inside a 24 m x 16 m hall with two pillars while a cart crosses the
+    hall; a 2-D lidar (n_beams over fov_deg, range noise sigma) is ray-cast against the walls; the odometry
+    drifts in scale and heading.  -> (records for replay.write_log, true poses [n,3] with yaw in degrees)."""
+    rng = _rng(seed)
+
+    def box(cx, cy, w, h):
+        x0, x1, y0, y1 = cx - w / 2, cx + w / 2, cy - h / 2, cy + h / 2
+        return [((x0, y0), (x1, y0)), ((x1, y0), (x1, y1)), ((x1, y1), (x0, y1)), ((x0, y1), (x0, y0))]
+
+    static = box(0.0, 0.0, 24.0, 16.0) + box(-4.0, 2.5, 1.0, 1.0) + box(5.0, -3.0, 1.5, 0.8)
+    beams = np.radians(np.linspace(-fov_deg / 2, fov_deg / 2, n_beams))
+    records, truth = [], []
+    odo = np.zeros(3)
+    prev = None
+    for k in range(n_frames):
+        a = 2 * np.pi * k * step / (2 * np.pi * 5.0)                 # circle of radius 5 m
+        pose = np.array([5.0 * np.cos(a) - 5.0, 5.0 * np.sin(a), np.degrees(a) + 90.0])
+        pose[2] = (pose[2] + 180.0) % 360.0 - 180.0
+        segs = static + box(-9.0 + 0.45 * k, -5.5, 0.8, 0.5)          # the cart
+        p0 = np.array([s[0] for s in segs]); p1 = np.array([s[1] for s in segs])
+        th = np.radians(pose[2]) + beams
+        d = np.stack([np.cos(th), np.sin(th)], 1)                     # [b,2]
+        e = p1 - p0                                                   # [m,2]
+        w = p0[None, :, :] - pose[None, None, :2]                     # [1,m,2]
+        den = d[:, None, 0] * e[None, :, 1] - d[:, None, 1] * e[None, :, 0]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (w[:, :, 0] * e[None, :, 1] - w[:, :, 1] * e[None, :, 0]) / den
+            u = (w[:, :, 0] * d[:, None, 1] - w[:, :, 1] * d[:, None, 0]) / den
+        t = np.where((den != 0) & (t > 0.05) & (u >= 0) & (u <= 1), t, np.inf)
+        r = t.min(1)
+        ok = r < max_range
+        r = r[ok] + rng.normal(0, sigma, ok.sum())
+        pts = np.stack([r * np.cos(beams[ok]), r * np.sin(beams[ok])], 1)     # sensor frame
+        if prev is not None:                                          # odometry: true motion with drift
+            dth = np.radians(prev[2])
+            dx, dy = pose[0] - prev[0], pose[1] - prev[1]
+            fx = (np.cos(dth) * dx + np.sin(dth) * dy) * odo_scale
+            fy = (-np.sin(dth) * dx + np.cos(dth) * dy) * odo_scale
+            oth = np.radians(odo[2])
+            odo[0] += np.cos(oth) * fx - np.sin(oth) * fy
+            odo[1] += np.sin(oth) * fx + np.cos(oth) * fy
+            odo[2] += ((pose[2] - prev[2] + 180.0) % 360.0 - 180.0) + odo_yaw_bias_deg
+            odo[2] = (odo[2] + 180.0) % 360.0 - 180.0
+        else:
+            odo = pose.copy()
+        prev = pose
+        records.append(dict(stamp=k, x=odo[0], y=odo[1], th=odo[2], image="img%04d.png" % k, front=pts,
+                            left=np.zeros((0, 2)), right=np.zeros((0, 2))))
+        truth.append(pose)
+    return records, np.array(truth)
