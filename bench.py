@@ -77,11 +77,19 @@ def main():
     assert world == args.gpus, "WORLD_SIZE %d != --gpus %d" % (world, args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the NDT core has no CPU fallback")
+    # NDT_BENCH_REHEARSAL=1: every rank on device 0 over gloo -- only to walk the N > 1 code path on a
+    # one-GPU box (RCCL refuses two ranks on one device); its numbers mean nothing.
+    rehearsal = world > 1 and os.environ.get("NDT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     cfg = synth.CONFIGS["C3"]
     B, n_scan = args.batch, cfg["n_scan"]

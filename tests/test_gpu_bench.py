@@ -33,3 +33,20 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["value"] > 100 * c["value"]
     assert 0 < d["map_build_ms"] < d["ms_per_step"]
     assert d["parity"]["max_dpos_m"] <= 1e-4 and d["parity"]["max_dyaw_rad"] <= 1e-4
+
+
+def test_two_rank_path_walks_through_on_one_gpu():
+    """N > 1 code path (sharded scans, gather of the result records on a side stream, MAX over ranks, rank 0
+    prints) rehearsed with both ranks on device 0 over gloo; the real run uses RCCL, one rank per GPU."""
+    env = dict(os.environ, NDT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["scans_per_gpu"] == 256 and "x2" in d["config"]["parallelism"]
+    assert "cpu_baseline" not in d                     # the CPU leg runs at N = 1 only
