@@ -150,3 +150,35 @@ def test_make_map_feeds_the_target_on_the_device(ctx, oracle):
     gm = capi.Map(ctx, filt_gpu, capi.default_params(resolution=0.5))
     assert gm.info().n_valid > 20
     gm.close()
+
+
+def test_wide_spans_and_degenerate_clouds(ctx, oracle):
+    """Tree depths far beyond a room (a point 3e6 m away: 26 levels), every point in one voxel (all inserts hit
+    one set entry), exact duplicates, and a base cloud much larger than the test cloud."""
+    rng = np.random.default_rng(17)
+    base, test = scene(rng, 4000, 3000)
+    far = np.array([[3.0e6, -2.5e6]], np.float32)
+    for b, t in ((np.concatenate([base, far]), test), (base, np.concatenate([test[:100], far, test[100:]])),
+                 (np.concatenate([far, base]), test)):
+        got = ctx.difference_extraction(b, t, 0.05)
+        assert got.tobytes() == expect_difference(oracle, b, t, 0.05).tobytes()
+    one = (np.float32(2.0) + rng.random((5000, 2)).astype(np.float32) * np.float32(0.01)).astype(np.float32)
+    got = ctx.difference_extraction(one[:3000], one[3000:], 0.05)
+    assert got.tobytes() == expect_difference(oracle, one[:3000], one[3000:], 0.05).tobytes()
+    dup = np.repeat(base[:50], 40, axis=0)
+    got = ctx.difference_extraction(dup, np.concatenate([dup[::7], test[:200]]), 0.05)
+    assert got.tobytes() == expect_difference(oracle, dup, np.concatenate([dup[::7], test[:200]]), 0.05).tobytes()
+    big, small = scene(rng, 150000, 2000, spread=40.0)
+    got = ctx.difference_extraction(big, small, 0.05)
+    assert got.tobytes() == expect_difference(oracle, big, small, 0.05).tobytes()
+
+
+def test_make_map_is_repeatable_and_reuses_its_buffers(ctx, oracle):
+    """Calls of different sizes back to back on one context (scratch grows and is reused, the pinned job table
+    of the previous call is waited for) give the same clouds as fresh calls."""
+    rng = np.random.default_rng(23)
+    sets = [submap_scans(rng, n, w, m) for n, w, m in ((4, 300, 10), (9, 2500, 80), (3, 100, 5), (14, 900, 30))]
+    refs = [oracle.make_map(s, True, True, True, 0.05, 0.2) for s in sets]
+    for _ in range(2):
+        for s, r in zip(sets, refs):
+            assert ctx.make_map(s, True, True, True, 0.05, 0.2).tobytes() == r.tobytes()
