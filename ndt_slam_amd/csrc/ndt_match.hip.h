@@ -27,9 +27,15 @@
 // ------------------------------------------------------------------------------------------
 constexpr int kBlock = 1024;
 constexpr int kWaves = kBlock / 64;
-constexpr int kSub = 4;                      // a lane's points are cut into kSub runs -> kSub units per wave
+#ifndef NDT_KSUB
+#define NDT_KSUB 4
+#endif
+constexpr int kSub = NDT_KSUB;               // a lane's points are cut into kSub runs -> kSub units per wave
 constexpr int kUnits = kWaves * kSub;        // units per pass
-constexpr int kMaxHelpers = 15;              // helper workgroups per scan, hard limit (64 units: 4 each)
+#ifndef NDT_MAX_HELPERS_BUILD
+#define NDT_MAX_HELPERS_BUILD 15
+#endif
+constexpr int kMaxHelpers = NDT_MAX_HELPERS_BUILD;   // helper workgroups per scan, hard limit (64 units: 4 each)
 #ifndef NDT_IDLE_MAX
 #define NDT_IDLE_MAX 800           // idle helper back-off: 4 us doubling up to 8 us (100 MHz ticks)
 #endif
@@ -728,15 +734,17 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         ubeg = uend;
       }
       if (aborted) break;
-      // pass total: the units in four groups of 16, each summed in unit order by one lane per value,
-      // then the four partial sums in order; wave 0 goes straight on to the optimiser step
-      static_assert(kUnits == 64, "four groups of 16 units");
+      // pass total: the units in kSub groups of 16, each summed in unit order by one lane per value,
+      // then the partial sums in group order; wave 0 goes straight on to the optimiser step
+      static_assert(kSub * 12 <= 64 && kUnits == 16 * kSub, "one lane per (group, value)");
       if (threadIdx.x < 64) {
-        const int j = lane % 12, grp = lane / 12;             // lanes 48..63: nothing to add
+        const int j = lane % 12, grp = lane / 12;             // lanes kSub*12..63: nothing to add
         double part = 0.0;
-        if (lane < 48) for (int v = 16 * grp; v < 16 * grp + 16; ++v) part += L.wpart[v * 12 + j];
-        const double p1 = __shfl(part, j + 12), p2 = __shfl(part, j + 24), p3 = __shfl(part, j + 36);
-        if (lane < 12) L.tot[lane] = ((part + p1) + p2) + p3;
+        if (lane < kSub * 12) for (int v = 16 * grp; v < 16 * grp + 16; ++v) part += L.wpart[v * 12 + j];
+        double total = part;
+#pragma unroll
+        for (int g = 1; g < kSub; ++g) total += __shfl(part, j + 12 * g);
+        if (lane < 12) L.tot[lane] = total;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
