@@ -125,7 +125,6 @@ def main():
     bctx.set_stream(bstream.cuda_stream)
     gmaps = [capi.Map(bctx, params=prm, dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8) for _ in range(2)]
     gmap = gmaps[0]
-    ev_used = [torch.cuda.Event() for _ in range(2)]        # the matches that read map k have finished
     torch.cuda.synchronize()
     solo_build_ms = []
     for _ in range(3):                                      # the build alone, nothing else on the GPU
@@ -140,7 +139,8 @@ def main():
         gm = gmaps[i & 1]
         # a2: rebuild the voxel grid of this step in place, as soon as the matches of step i - 2 (the last
         # readers of this grid) are done
-        bstream.wait_event(ev_used[i & 1])
+        if i >= 2:
+            bstream.wait_event(ev_a[2 * (i - 2) + 1])
         ev_m[2 * i].record(bstream)
         gm.rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
         ev_m[2 * i + 1].record(bstream)
@@ -153,8 +153,7 @@ def main():
         ev_a[2 * i].record(stream)
         gm.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, len(scans), d_init.data_ptr(),
                            out.data_ptr(), stream=stream.cuda_stream)
-        ev_a[2 * i + 1].record(stream)
-        ev_used[i & 1].record(stream)
+        ev_a[2 * i + 1].record(stream)                 # (also what the rebuild of step i + 2 waits for)
         if world > 1:    # gather of poses (the only collective on this path)
             side.wait_stream(stream)
             with torch.cuda.stream(side):
