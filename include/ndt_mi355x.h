@@ -201,7 +201,7 @@ int ndt_fuse_batch_dev(ndt_ctx *ctx, const ndt_result *results_dev, const double
                        int B, const ndt_fuse_params *prm, double *fused_pose_dev, double *cov_dev,
                        int *successful_dev, void *stream);
 
-/* SURVEY.md 8f row f3 (part) -- replaces PCFilter::remove_neighborPoint(cloud_base, point_list)
+/* SURVEY.md 8f row f3 (the all-pairs step on its own) -- replaces PCFilter::remove_neighborPoint(cloud_base, point_list)
  * (include/ndt_slam/PCFilter.h:29-56, called from Submap::makeMap, src/PointCloudMap.cpp:27): the points
  * of `base` with no point of `list` closer than thre_neighbor (PCLUtil::distance_points' float32
  * distance, include/ndt_slam/PCLUtil.h:21-23, strict <), in input order, packed as float2.

@@ -418,7 +418,7 @@ fuse_kernel(const ndt_result *__restrict__ res, const double *__restrict__ pred_
 
 
 // ------------------------------------------------------------------------------------------
-// f3 (part): PCFilter::remove_neighborPoint (include/ndt_slam/PCFilter.h:29-56) -- keep the points
+// f3 (the all-pairs step on its own): PCFilter::remove_neighborPoint (include/ndt_slam/PCFilter.h:29-56) -- keep the points
 // of `base` that have no point of `list` closer than thre_neighbor, in input order.  The
 // reference tests every pair (O(n*m) on the CPU, the largest cost outside NDT when moving
 // objects are removed, src/PointCloudMap.cpp:15-39); here one lane per base point walks the list
