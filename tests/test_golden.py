@@ -80,3 +80,69 @@ def test_hip_path_matches_golden(gold):
         assert s == pytest.approx(e[0], rel=1e-11) and pairs == e[13]
         assert g == pytest.approx(e[1:4], rel=1e-8, abs=1e-9 * np.abs(e[1:4]).max())
         assert H.ravel() == pytest.approx(e[4:13], rel=1e-8, abs=1e-9 * np.abs(e[4:13]).max())
+
+
+# ---- rows around the match: tests/golden/front_golden.npz, made by make_front_golden.py ----
+FRONT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "front_golden.npz")
+
+
+@pytest.fixture(scope="module")
+def front():
+    return np.load(FRONT)
+
+
+def _sub_scans(front):
+    off = front["sub_offsets"]
+    return [front["sub_scans"][int(off[i]):int(off[i + 1])] for i in range(len(off) - 1)]
+
+
+def _replay(front, ops, estim=None):
+    from ndt_slam_amd import replay
+    c = np.concatenate([[0], np.cumsum(front["replay_counts"])])
+    scans = [replay.Scan2D(front["replay_front"][int(c[i]):int(c[i + 1])], sid=i, pose=replay.Pose2D(*front["replay_odo"][i]))
+             for i in range(len(c) - 1)]
+    params = dict(replay.LAUNCH_PARAMS, end_frame=len(scans), sepThre=4.0)
+    if estim is not None:
+        estim = estim(params)
+    sl = replay.SlamLauncher(ops, estim=estim, **params)
+    poses = sl.run(scans)
+    return np.array([[p.tx, p.ty, p.th] for p in poses]), sl
+
+
+def test_front_generator_is_stable(front):
+    from ndt_slam_amd import synth
+    scans = synth.submap_scans(5, 700, seed=77)
+    assert np.array_equal(np.concatenate(scans), front["sub_scans"])
+    recs, _ = synth.replay_records(n_frames=12, n_beams=181, step=0.6)
+    assert np.array_equal(np.concatenate([r["front"] for r in recs]), front["replay_front"])
+
+
+def test_oracle_reproduces_front_golden(oracle, front):
+    from replay_helpers import OracleEstimator, OracleOps
+    scans = _sub_scans(front)
+    assert np.array_equal(oracle.difference_indices(np.concatenate([scans[0], scans[2]]), scans[1], 0.05), front["diff_idx"])
+    for name, (first, newest) in (("first_newest", (True, True)), ("later_newest", (False, True)), ("later_closed", (False, False))):
+        assert oracle.make_map(scans, first, newest, True, 0.05, 0.2).tobytes() == front["mm_" + name].tobytes()
+    assert oracle.approx_voxel_filter(front["mm_first_newest"], 0.05).tobytes() == front["filtered"].tobytes()
+    for v in front["predict"]:
+        mo, pr = oracle.predict(v[0:3], v[3:6], v[6:9])
+        assert np.array_equal(mo, v[9:12]) and np.array_equal(pr, v[12:15])
+    poses, sl = _replay(front, OracleOps(oracle), lambda p: OracleEstimator(oracle, p))
+    assert poses == pytest.approx(front["replay_poses"], abs=1e-9)
+    assert sl.smat.accepted == front["replay_accepted"].tolist() and len(sl.pcmap.submaps) == int(front["replay_submaps"])
+
+
+@pytest.mark.gpu
+def test_hip_path_matches_front_golden(front):
+    from ndt_slam_amd import capi
+    ctx = capi.Context(0)
+    scans = _sub_scans(front)
+    got = ctx.difference_extraction(np.concatenate([scans[0], scans[2]]), scans[1], 0.05)
+    assert got.tobytes() == scans[1][np.sort(front["diff_idx"])].tobytes()      # same set, input order
+    for name, (first, newest) in (("first_newest", (True, True)), ("later_newest", (False, True)), ("later_closed", (False, False))):
+        assert ctx.make_map(scans, first, newest, True, 0.05, 0.2).tobytes() == front["mm_" + name].tobytes()
+    assert ctx.prefilter(front["mm_first_newest"], 0.05).tobytes() == front["filtered"].tobytes()
+    poses, sl = _replay(front, ctx)
+    d = poses - front["replay_poses"]
+    assert np.abs(d[:, :2]).max() <= 1e-4 and np.abs(np.radians(d[:, 2])).max() <= 1e-4      # north_star tolerance
+    assert sl.smat.accepted == front["replay_accepted"].tolist() and len(sl.pcmap.submaps) == int(front["replay_submaps"])
