@@ -13,7 +13,8 @@
 //   * a point's voxel key is computed with the box minimum of the moment it was inserted, exactly as
 //     genOctreeKeyforPoint does in fp64, and moved into the final frame by the integer shifts of the later
 //     growth steps (the old root becomes child (!upX, !upY, !upZ) of the new one);
-//   * "leaf exists in the previous buffer" is membership in a hash set of the base cloud's final keys.
+//   * "leaf exists in the previous buffer" is membership in a hash set of the base cloud's final keys (in LDS
+//     when the cloud occupies few enough voxels, else in HBM).
 //
 // One 1024-thread workgroup per triple does frame, keys, set and difference, the triples of a submap side by
 // side; the neighbour removal and the concatenation then run over 256-point units on the whole chip.
@@ -21,7 +22,7 @@
 // point.  (The tests check all of this against a literal two-buffer pointer octree.)
 
 constexpr int kMmBlock = 1024, kMmWaves = kMmBlock / 64, kMmEvents = 40, kMmMaxDepth = 30, kMmTile = 1024;
-constexpr int kMmUnit = 256, kMmPer = 4, kMmGroup = 8, kMmIns = 8;
+constexpr int kMmUnit = 256, kMmPer = 4, kMmGroup = 8, kMmIns = 8, kMmLdsTab = 16384;
 constexpr unsigned long long kMmEmpty = ~0ull;
 
 struct MmJob {
@@ -112,6 +113,8 @@ __global__ void __launch_bounds__(kMmBlock)
 make_map_diff_kernel(const MmJob *__restrict__ jobs, double res) {
   __shared__ MmFrame F;
   __shared__ int wcnt[kMmPer][kMmWaves];
+  __shared__ unsigned long long ltab[kMmLdsTab];
+  __shared__ int lfill, lover;
   const MmJob J = jobs[blockIdx.x];
   const int tid = threadIdx.x, lane = tid & 63;
   const int nA = (int)(J.n0 + J.n1), N = nA + (int)J.nb;
@@ -206,9 +209,42 @@ make_map_diff_kernel(const MmJob *__restrict__ jobs, double res) {
   }
   const double rinv = 1.0 / res;
 
-  // ---- 2. voxels of the base cloud into the set (kMmIns probes in flight per thread: the set lives in HBM and
-  // every probe is a round trip) ----
-  for (int q0 = tid; q0 < nA; q0 += kMmIns * kMmBlock) {
+  // ---- 2. voxels of the base cloud into the set ----
+  // A scan revisits the same few thousand voxels, so the set is first tried in LDS (16k entries, probes cost a
+  // fraction of a microsecond); only when the base cloud occupies more than 12k voxels is it rebuilt in the
+  // HBM table the host prepared (kMmIns probes in flight per thread there: every probe is a round trip).
+  for (int i = tid; i < kMmLdsTab; i += kMmBlock) ltab[i] = kMmEmpty;
+  if (tid == 0) { lfill = 0; lover = 0; }
+  __syncthreads();
+  for (int q0 = tid; q0 - tid < nA; q0 += kMmIns * kMmBlock) {   // (whole waves: the duplicate filter is a shuffle)
+    float2 p[kMmIns];
+#pragma unroll
+    for (int k = 0; k < kMmIns; ++k) {                            // the loads of a batch in flight together
+      const int q = q0 + k * kMmBlock;
+      p[k] = make_float2(0.f, 0.f);
+      if (q < nA) p[k] = mm_fetch(J, q);
+    }
+#pragma unroll
+    for (int k = 0; k < kMmIns; ++k) {
+      const int q = q0 + k * kMmBlock;
+      bool open = q < nA && isfinite(p[k].x) && isfinite(p[k].y);
+      const unsigned long long key = open ? mm_key(F, p[k], q, res, rinv) : kMmEmpty;
+      const unsigned long long prev = __shfl_up(key, 1);
+      if (lane > 0 && prev == key) open = false;
+      if (open && !lover) {
+        unsigned h = mm_hash(key) & (unsigned)(kMmLdsTab - 1);
+        for (int t = 0; t < kMmLdsTab; ++t) {
+          const unsigned long long old = atomicCAS(&ltab[h], kMmEmpty, key);
+          if (old == kMmEmpty) { if (atomicAdd(&lfill, 1) >= kMmLdsTab * 3 / 4) lover = 1; break; }
+          if (old == key || lover) break;
+          h = (h + 1u) & (unsigned)(kMmLdsTab - 1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const bool in_lds = lover == 0;
+  for (int q0 = tid; !in_lds && q0 < nA; q0 += kMmIns * kMmBlock) {
     unsigned long long key[kMmIns]; unsigned h[kMmIns]; bool open[kMmIns];
 #pragma unroll
     for (int k = 0; k < kMmIns; ++k) {
@@ -240,6 +276,7 @@ make_map_diff_kernel(const MmJob *__restrict__ jobs, double res) {
   __syncthreads();
 
   // ---- 3. points of the test cloud in voxels the base cloud does not occupy ----
+  const unsigned tmask = in_lds ? (unsigned)(kMmLdsTab - 1) : J.tab_mask;
   int nd = 0;
   for (int c0 = 0; c0 < (int)J.nb; c0 += kMmPer * kMmBlock) {
     float2 p[kMmPer]; unsigned long long key[kMmPer]; unsigned h[kMmPer]; bool open[kMmPer], isnew[kMmPer];
@@ -251,19 +288,21 @@ make_map_diff_kernel(const MmJob *__restrict__ jobs, double res) {
       open[k] = i < (int)J.nb && isfinite(p[k].x) && isfinite(p[k].y);
       isnew[k] = open[k];
       key[k] = open[k] ? mm_key(F, p[k], nA + i, res, rinv) : 0ull;
-      h[k] = mm_hash(key[k]) & J.tab_mask;
+      h[k] = mm_hash(key[k]) & tmask;
     }
-    for (unsigned t = 0; t <= J.tab_mask; ++t) {
+    for (unsigned t = 0; t <= tmask; ++t) {
       unsigned long long cur[kMmPer];
 #pragma unroll
-      for (int k = 0; k < kMmPer; ++k)
-        cur[k] = open[k] ? __hip_atomic_load(&J.tab[h[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kMmEmpty;
+      for (int k = 0; k < kMmPer; ++k) {
+        if (in_lds) cur[k] = open[k] ? ltab[h[k]] : kMmEmpty;
+        else cur[k] = open[k] ? __hip_atomic_load(&J.tab[h[k]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kMmEmpty;
+      }
       bool any = false;
 #pragma unroll
       for (int k = 0; k < kMmPer; ++k) {
         if (open[k] && cur[k] == key[k]) { isnew[k] = false; open[k] = false; }
         if (cur[k] == kMmEmpty) open[k] = false;
-        h[k] = (h[k] + 1u) & J.tab_mask;
+        h[k] = (h[k] + 1u) & tmask;
         any = any || open[k];
       }
       if (!any) break;
