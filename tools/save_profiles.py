@@ -1,5 +1,5 @@
 """Copy the rocprofv3 outputs of a gpurun call into profiles/ (tracked) and derive r01_traffic.json.
-Expects gpurun_out/{r1stats,r1fetch,r1write,r1lm}/run_*.csv and gpurun_out/{r1stats,r1fetch,r1write,bench_r1}.log."""
+Expects gpurun_out/{r1stats,r1fetch,r1write,r1lm,r1def}/run_*.csv and gpurun_out/{r1stats,r1fetch,r1write,bench_r1}.log."""
 import csv, json, os, shutil
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(R, "gpurun_out"), os.path.join(R, "profiles")
@@ -48,3 +48,26 @@ for n in ("r01_stats.log", "r01_bench.json"):
 for name, r in st.items():
     if name.startswith("map_") or name.startswith("scan_") or name.startswith("fill_"):
         print("  %-28s %6.1f us" % (name, float(r["AverageNs"]) / 1e3))
+
+# the default command itself (gpurun_out/r1def): summary + the match-kernel dispatches labelled by launch kind
+dd = os.path.join(G, "r1def")
+if os.path.exists(os.path.join(dd, "run_kernel_trace.csv")):
+    shutil.copy(os.path.join(dd, "run_kernel_stats.csv"), os.path.join(P, "r01_default_cmd_kernel_stats.csv"))
+    rows = sorted(csv.DictReader(open(os.path.join(dd, "run_kernel_trace.csv"))), key=lambda r: int(r["Start_Timestamp"]))
+    al = [r for r in rows if "ndt_align" in r["Kernel_Name"]]
+    line = [l for l in open(os.path.join(G, "r1def.log")) if l.startswith("{")][-1]
+    d = json.loads(line)
+    kinds = (["warm-up"] * d["warmup"] + ["timed step"] * d["steps"] + ["single scan (configs[1])"] * 5 +
+             ["front-end step (filtered raw scans)"] * 5)
+    assert len(al) == len(kinds), (len(al), len(kinds))
+    with open(os.path.join(P, "r01_default_cmd_align_dispatches.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Dispatch_Id", "Kernel", "Workgroup_Size", "Grid_Size", "Start_Timestamp", "End_Timestamp", "Duration_us", "launch"])
+        for r, k in zip(al, kinds):
+            w.writerow([r["Dispatch_Id"], "ndt_align_kernel", r["Workgroup_Size_X"], r["Grid_Size_X"], r["Start_Timestamp"],
+                        r["End_Timestamp"], "%.3f" % ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3), k])
+    open(os.path.join(P, "r01_default_cmd.log"), "w").write(line)
+    timed = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r, k in zip(al, kinds) if k == "timed step"]
+    print("default command: timed steps average %.1f us in the trace, %.1f us from its HIP events" % (
+        sum(timed) / len(timed), d["roofline"]["kernel_ms"] * 1e3))
+
