@@ -12,7 +12,10 @@
  *
  * Threading: a context is bound to one device and one host thread; all GPU work runs on the
  * context's stream (or the stream passed to the *_dev calls).  Host-pointer calls are
- * synchronous on return; *_dev calls are asynchronous on their stream.
+ * synchronous on return; *_dev calls are asynchronous on their stream.  A context owns one set of
+ * scratch buffers: *_dev calls of ONE context on different streams are serialised by the library (the
+ * later call's stream waits for the earlier call's kernels); to have two batches in flight at the
+ * same time use two contexts (a map may be read by any context of its device).
  */
 #ifndef NDT_MI355X_H_
 #define NDT_MI355X_H_
@@ -36,7 +39,7 @@ enum ndt_status {
 /* Parameters of the path.  The first four are the ROS parameters the reference's constructor
  * reads and hands to PCL (include/ndt_slam/PoseEstimator.h:63-84; values in
  * ndt_mapping.launch:32-36); the rest are PCL defaults and the version-sensitive switches of
- * SURVEY.md 8c (defaults = PCL <= 1.10 as surveyed). */
+ * SURVEY.md 8c; ndt_default_params = ndt_params_pcl110 (presets below). */
 typedef struct ndt_params {
   float  resolution;        /* PoseEstimator.h:81  ndt.setResolution             */
   double step_size;         /* PoseEstimator.h:79  ndt.setStepSize               */
@@ -77,9 +80,18 @@ typedef struct ndt_result {
                          passes and the getHessian pass, which are fused here)                     */
   int    converged;   /* hasConverged() (src/PoseEstimator.cpp:44)                                 */
   int    status;      /* ndt_status of this match                                                  */
-  int    pad_;
+  int    flags;       /* NDT_FLAG_* bits: which data path the match took (results do not depend on it)    */
   double kbar;        /* mean in-radius cells per point-evaluation (roofline accounting)           */
 } ndt_result;
+
+/* ndt_result.flags */
+enum ndt_result_flags {
+  NDT_FLAG_WINDOW_SPILL  = 1,  /* occupied voxels of the scan's window had no LDS record: points that reached
+                                  them read the cell table from HBM                                          */
+  NDT_FLAG_REGION_CLIPPED = 2, /* the scan's voxel bounding box exceeded the LDS window (16384 cells): points
+                                  outside it read the cell table from HBM                                    */
+  NDT_FLAG_UNSORTED      = 4   /* scan above 20000 points: passes read it in input order                     */
+};
 
 typedef struct ndt_map_info {
   int min_bx, min_by, div_x, div_y;
@@ -91,14 +103,32 @@ typedef struct ndt_map_info {
 typedef struct ndt_ctx ndt_ctx;
 typedef struct ndt_map ndt_map;
 
-/* PCL-side defaults + include/ndt_slam/PoseEstimator.h:63-64 constructor defaults. */
+/* include/ndt_slam/PoseEstimator.h:63-64 constructor defaults + the PCL-side values, as one of three
+ * presets of the version-sensitive switches (PCL is un-vendored and unpinned, CMakeLists.txt:21; the
+ * reference compiles only against PCL <= 1.10, include/ndt_slam/PoseEstimator.h:72-73):
+ *   ndt_params_pcl110   PCL 1.9 / 1.10 (Ubuntu 20.04, the likely build): VoxelGridCovariance::Leaf() starts
+ *                       cov_ at the identity (cov_init_identity = 1), (n-1)/n normalisation
+ *                       (cov_unbiased = 0), SSE transformPointCloud (transform_sse = 1)
+ *   ndt_params_pcl18    PCL <= 1.8: the same voxel statistics, scalar transformPointCloud (transform_sse = 0)
+ *   ndt_params_pcl_new  PCL >= 1.11: cov_ starts at zero, /(n-1) (cov_unbiased = 1), SSE transform
+ * ndt_default_params is ndt_params_pcl110. */
 int ndt_default_params(ndt_params *p);
+int ndt_params_pcl110(ndt_params *p);
+int ndt_params_pcl18(ndt_params *p);
+int ndt_params_pcl_new(ndt_params *p);
 
 /* One context per process and device (one process per GPU).  device = HIP ordinal. */
 int ndt_ctx_create(int device, ndt_ctx **out);
 int ndt_ctx_destroy(ndt_ctx *ctx);               /* destroy the context's maps first */
 const char *ndt_last_error(const ndt_ctx *ctx);   /* ctx may be NULL: last global error */
 void *ndt_ctx_stream(ndt_ctx *ctx);               /* hipStream_t the context works on   */
+/* Tuning of the match launch (defaults are right for whole-GPU batches):
+ *   NDT_OPT_MAX_HELPERS  0..15  workgroups that may join the passes of one unfinished scan; 0 = no work sharing
+ *   NDT_OPT_WORKGROUPS   0..#CU workgroups per match launch (0 = one per CU); a smaller value leaves CUs to
+ *                               other streams
+ * Results never depend on either (unit totals are summed in unit order whoever computed them). */
+enum ndt_option { NDT_OPT_MAX_HELPERS = 1, NDT_OPT_WORKGROUPS = 2 };
+int ndt_ctx_set_option(ndt_ctx *ctx, int option, long long value);
 /* Make the context work on a caller-owned hipStream_t (e.g. the stream a host framework already
  * orders its copies on); NULL restores the context's own stream. */
 int ndt_ctx_set_stream(ndt_ctx *ctx, void *stream);

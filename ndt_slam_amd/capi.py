@@ -47,12 +47,14 @@ RESULT_DTYPE = np.dtype([
     ("pose", "f8", 3), ("T00", "f4"), ("T10", "f4"), ("T03", "f4"), ("T13", "f4"),
     ("fitness", "f8"), ("trans_prob", "f8"), ("score", "f8"), ("H", "f8", 9), ("p", "f8", 3),
     ("iters", "i4"), ("evals", "i4"), ("ref_evals", "i4"), ("converged", "i4"), ("status", "i4"),
-    ("pad_", "i4"), ("kbar", "f8")], align=True)
+    ("flags", "i4"), ("kbar", "f8")], align=True)
 RESULT_BYTES = RESULT_DTYPE.itemsize
+FLAG_WINDOW_SPILL, FLAG_REGION_CLIPPED, FLAG_UNSORTED = 1, 2, 4      # ndt_result.flags
+OPT_MAX_HELPERS, OPT_WORKGROUPS = 1, 2                                # ndt_ctx_set_option
 
 EXPORTS = [
-    "ndt_default_params", "ndt_ctx_create", "ndt_ctx_destroy", "ndt_last_error", "ndt_ctx_stream",
-    "ndt_ctx_set_stream",
+    "ndt_default_params", "ndt_params_pcl110", "ndt_params_pcl18", "ndt_params_pcl_new", "ndt_ctx_create", "ndt_ctx_destroy", "ndt_last_error", "ndt_ctx_stream",
+    "ndt_ctx_set_stream", "ndt_ctx_set_option",
     "ndt_map_build", "ndt_map_build_dev", "ndt_map_destroy", "ndt_map_info_get", "ndt_map_export",
     "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_trace", "ndt_eval_at",
     "ndt_fitness_at", "ndt_last_timing", "ndt_prefilter", "ndt_prefilter_batch_dev",
@@ -72,7 +74,8 @@ def lib():
                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
     L = C.CDLL(LIB_PATH)
     vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
-    L.ndt_default_params.argtypes = [C.POINTER(Params)]
+    for name in ("ndt_default_params", "ndt_params_pcl110", "ndt_params_pcl18", "ndt_params_pcl_new"):
+        getattr(L, name).argtypes = [C.POINTER(Params)]
     L.ndt_ctx_create.argtypes = [i, C.POINTER(vp)]
     L.ndt_ctx_destroy.argtypes = [vp]
     L.ndt_last_error.restype = C.c_char_p
@@ -80,6 +83,7 @@ def lib():
     L.ndt_ctx_stream.restype = vp
     L.ndt_ctx_stream.argtypes = [vp]
     L.ndt_ctx_set_stream.argtypes = [vp, vp]
+    L.ndt_ctx_set_option.argtypes = [vp, i, C.c_longlong]
     L.ndt_map_build.argtypes = [vp, vp, sz, sz, C.POINTER(Params), C.POINTER(vp)]
     L.ndt_map_build_dev.argtypes = [vp, vp, sz, sz, C.POINTER(Params), C.POINTER(vp)]
     L.ndt_map_destroy.argtypes = [vp]
@@ -111,9 +115,14 @@ def lib():
     return L
 
 
-def default_params(**kw):
+PRESETS = {"default": "ndt_default_params", "pcl110": "ndt_params_pcl110", "pcl18": "ndt_params_pcl18",
+           "pcl_new": "ndt_params_pcl_new"}
+
+
+def default_params(preset="default", **kw):
+    """ndt_params of a PCL-version preset (include/ndt_mi355x.h), fields overridden by keyword."""
     p = Params()
-    lib().ndt_default_params(C.byref(p))
+    getattr(lib(), PRESETS[preset])(C.byref(p))
     for k, v in kw.items():
         if not hasattr(p, k):
             raise AttributeError(k)
@@ -159,6 +168,10 @@ class Context:
     def set_stream(self, stream):
         """Order all work of this context on a caller-owned hipStream_t (int handle or None)."""
         self.check(lib().ndt_ctx_set_stream(self.h, stream), "ndt_ctx_set_stream")
+
+    def set_option(self, option, value):
+        """ndt_ctx_set_option: OPT_MAX_HELPERS (0 = no work sharing), OPT_WORKGROUPS (0 = one per CU)."""
+        self.check(lib().ndt_ctx_set_option(self.h, option, value), "ndt_ctx_set_option")
 
     def prefilter(self, xy, leaf):
         """pcl::ApproximateVoxelGrid on one scan ([n, 2] float32) -> filtered [m, 2] float32."""

@@ -14,74 +14,6 @@
 // ------------------------------------------------------------------------------------------
 constexpr int kPfSlots = 512;
 struct __attribute__((aligned(8))) PfSlot { int ix, iy, cnt; float cx, cy; int pad; };   // 24 B: one b128 + one b64 LDS read
-__global__ void __launch_bounds__(64)
-prefilter_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
-                 float leaf, float2 *__restrict__ tmp /* at the raw offsets */, unsigned *__restrict__ counts) {
-  __shared__ PfSlot slot[kPfSlots];
-  const int lane = threadIdx.x;
-  const unsigned long long lt = (1ull << lane) - 1ull;
-  const float inv = 1.0f / leaf;
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {
-    const unsigned long long o0 = offsets[b];
-    const int n = (int)(offsets[b + 1] - o0);
-    for (int h = lane; h < kPfSlots; h += 64) { PfSlot z; z.ix = 0; z.iy = 0; z.cnt = 0; z.cx = 0.f; z.cy = 0.f; z.pad = 0; slot[h] = z; }
-    __builtin_amdgcn_wave_barrier();
-    int nout = 0;
-    float2 pnext = make_float2(0.f, 0.f);
-    if (lane < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)lane);
-    for (int base = 0; base < n; base += 64) {
-      const int i = base + lane;
-      const bool active = i < n;
-      const float2 p = pnext;
-      if (i + 64 < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)(i + 64));   // next step's points in flight
-      const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
-      const unsigned h = ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);   // iz = 0
-      // lanes of this step that use the same slot, and this lane's turn among them
-      unsigned long long peers = __ballot(active);
-#pragma unroll
-      for (int bit = 0; bit < 9; ++bit) {
-        const unsigned long long one = __ballot(active && ((h >> bit) & 1u));
-        peers &= ((h >> bit) & 1u) ? one : ~one;
-      }
-      const int rank = __builtin_popcountll(peers & lt);
-      bool flushed = false;
-      float fx = 0.f, fy = 0.f;
-      for (int turn = 0; turn < 64; ++turn) {
-        if (!__ballot(active && rank >= turn)) break;
-        if (active && rank == turn) {
-          PfSlot e = slot[h];
-          if (e.cnt && (ix != e.ix || iy != e.iy)) {          // another voxel holds the slot: flush it
-            flushed = true; fx = e.cx / (float)e.cnt; fy = e.cy / (float)e.cnt;
-            e.cnt = 0; e.cx = 0.f; e.cy = 0.f;
-          }
-          e.ix = ix; e.iy = iy; e.cnt += 1; e.cx += p.x; e.cy += p.y;
-          slot[h] = e;
-        }
-        __builtin_amdgcn_wave_barrier();
-      }
-      const unsigned long long fb = __ballot(flushed);
-      if (flushed) tmp[o0 + (unsigned long long)(nout + __builtin_popcountll(fb & lt))] = make_float2(fx, fy);
-      nout += __builtin_popcountll(fb);
-    }
-    for (int h0 = 0; h0 < kPfSlots; h0 += 64) {              // what is left, in slot order
-      const PfSlot e = slot[h0 + lane];
-      const unsigned long long fb = __ballot(e.cnt > 0);
-      if (e.cnt > 0) tmp[o0 + (unsigned long long)(nout + __builtin_popcountll(fb & lt))] =
-          make_float2(e.cx / (float)e.cnt, e.cy / (float)e.cnt);
-      nout += __builtin_popcountll(fb);
-    }
-    if (lane == 0) counts[b] = (unsigned)nout;
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// The same machine on kPfWaves waves per scan.  The 512 slots are independent state machines; wave w
-// owns the slots with (slot mod kPfWaves) == w.  Every wave reads the whole scan 64 points at a
-// time (cheap: load, hash, ballot), queues the points of its own slots in order, and replays a
-// step whenever 64 are queued -- so the expensive part (turn-taking on the slot state) runs on a
-// quarter of the points per wave.  A flush is stored at the index of the point that caused it
-// (sparse copy) with a bit in an LDS bitmap; a prefix sum over the bitmap then writes the flushes in
-// the order of those indices, which is the order the sequential filter emits them in.
 constexpr int kPfWaveBits = 2, kPfWaves = 1 << kPfWaveBits, kPfQueue = 128, kPfMaxPoints = 1 << 18;   // bitmap: 32 KiB of LDS
 __global__ void __launch_bounds__(64 * kPfWaves)
 prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,

@@ -122,6 +122,7 @@ struct Lds {
   int hrank;                       // helper: order of registration on its scan
   int jnext, stop;                 // units of the open segment handed out so far; close the segment
   unsigned diag[2];                // diagnostic: ticks of fill_window's first two phases
+  int clipped;                     // owner: the scan's voxel bounding box did not fit the window
   double etab[64];
 };
 
@@ -159,6 +160,7 @@ __device__ __forceinline__ void compute_region(const MapView &M, const Tf32 &T0,
   __syncthreads();
   if (threadIdx.x == 0) {
     Region r = {0, 0, 0, 0, 0, 0};
+    L.clipped = 0;
     if (L.sbox[0] <= L.sbox[2]) {
       // clip the bbox to the padded map grid, add the slack, then fit the slot-table budget around
       // the bbox centre
@@ -169,6 +171,7 @@ __device__ __forceinline__ void compute_region(const MapView &M, const Tf32 &T0,
       long long w = x1 - x0 + 1, h = y1 - y0 + 1;
       if (w > 0 && h > 0) {
         if (w * h > kRegionCells) {
+          L.clipped = 1;
           long long w2 = w > 128 ? 128 : w;
           long long h2 = kRegionCells / w2; if (h2 > h) h2 = h;
           x0 += (w - w2) / 2; y0 += (h - h2) / 2; w = w2; h = h2;
@@ -781,7 +784,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       R_.ref_evals = S.ref_evals + 1;       // + the getHessian pass (src/PoseEstimator.cpp:56)
       R_.converged = S.converged;
       R_.status = aborted ? NDT_E_HIP : (n > 0 ? NDT_OK : NDT_E_ARG);
-      R_.pad_ = 0;
+      R_.flags = (L.RG.nspill > 0 ? NDT_FLAG_WINDOW_SPILL : 0) | (L.clipped ? NDT_FLAG_REGION_CLIPPED : 0) |
+                 ((n > 0 && pts == scan) ? NDT_FLAG_UNSORTED : 0);
       R_.kbar = (S.evals > 0 && n > 0) ? S.pairs / ((double)S.evals * (double)n) : 0.0;
       results[b] = R_;
       if (allow_helpers) {

@@ -78,7 +78,11 @@ struct ndt_ctx {
   void *h_mm = nullptr; size_t h_mm_cap = 0;           // pinned staging of the job table
   hipEvent_t ev_mm = nullptr; bool mm_pending = false; // job table upload of the previous call
   int num_cus = 0;
-  int helpers = 1;                                     // NDT_NO_HELPERS=1 disables work sharing (diagnostic)
+  int helpers = 1;                                     // NDT_OPT_MAX_HELPERS: helper workgroups per scan (0: no work sharing)
+  int workgroups = 0;                                  // NDT_OPT_WORKGROUPS: workgroups of a match launch (0: one per CU)
+  // The grow-only scratch above belongs to the context, not to a stream: a call on another stream than the
+  // previous one first waits for the previous user (ev_scratch).
+  hipEvent_t ev_scratch = nullptr; hipStream_t scratch_stream = nullptr; bool scratch_used = false;
 };
 
 struct ndt_map {
@@ -135,6 +139,17 @@ int ensure_t(ndt_ctx *ctx, T **p, size_t *cap_elems, size_t need_elems) {
   return rc;
 }
 
+// Scratch hand-over between streams (see ndt_ctx): call before the first and after the last use in an entry point.
+int scratch_begin(ndt_ctx *ctx, hipStream_t st) {
+  if (ctx->scratch_used && st != ctx->scratch_stream) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
+  return NDT_OK;
+}
+int scratch_end(ndt_ctx *ctx, hipStream_t st) {
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_scratch, st));
+  ctx->scratch_stream = st; ctx->scratch_used = true;
+  return NDT_OK;
+}
+
 OptParams opt_of(const ndt_params &p) {
   OptParams o;
   o.step_size = p.step_size; o.trans_eps = p.trans_eps; o.snap_thresh = p.snap_thresh;
@@ -178,7 +193,8 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   unsigned char *ws = (unsigned char *)ctx->d_ws;
   const int helpers = ctx->helpers;
   // one workgroup per CU (the LDS window allows no more); idle workgroups help unfinished scans
-  const int grid = helpers ? ctx->num_cus : (B < ctx->num_cus ? B : ctx->num_cus);
+  const int ncu = ctx->workgroups > 0 ? ctx->workgroups : ctx->num_cus;
+  const int grid = helpers ? ncu : (B < ncu ? B : ncu);
 #define NDT_LAUNCH(S_, I_)                                                                           \
   ndt_align_kernel<S_, I_><<<grid, kBlock, 0, st>>>(V, O, scans, offsets, B, shared_scan, inits, out, trace, \
                                                     trace_cap, trace_rows, sorted, ws, helpers, prof)
@@ -202,28 +218,42 @@ int upload_exp_table(ndt_ctx *ctx) {
 
 extern "C" {
 
-int ndt_default_params(ndt_params *p) {
-  if (!p) return NDT_E_ARG;
+// Presets of the version-sensitive PCL behaviour.  The reference compiles only
+// against PCL <= 1.10 (boost::shared_ptr clouds, include/ndt_slam/PoseEstimator.h:72-73), most likely 1.10.0.
+static void params_common(ndt_params *p) {
   memset(p, 0, sizeof(*p));
-  p->resolution = 1.0f; p->step_size = 0.1; p->trans_eps = 0.01; p->max_iter = 35;
+  p->resolution = 1.0f; p->step_size = 0.1; p->trans_eps = 0.01; p->max_iter = 35;   // PoseEstimator.h:63-64
   p->outlier_ratio = 0.55; p->min_pts = 6; p->eig_mult = 0.01;
-  p->cov_unbiased = 0; p->cov_init_identity = 0; p->conv_ge = 0; p->radius_inclusive = 0;
-  p->transform_sse = 0; p->stale_h_ang = 1; p->snap_thresh = 10e-5; p->mt_max_iter = 10;
-  p->mt_mu = 1.e-4; p->mt_nu = 0.9;
+  p->conv_ge = 0; p->radius_inclusive = 0; p->stale_h_ang = 1;
+  p->snap_thresh = 10e-5; p->mt_max_iter = 10; p->mt_mu = 1.e-4; p->mt_nu = 0.9;
+}
+
+int ndt_params_pcl110(ndt_params *p) {      // PCL 1.9 / 1.10: Leaf() starts cov_ at the identity, biased
+  if (!p) return NDT_E_ARG;                 // normalisation, SSE transformPointCloud
+  params_common(p);
+  p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 1;
   return NDT_OK;
 }
 
+int ndt_params_pcl18(ndt_params *p) {       // PCL <= 1.8: the same voxel statistics, scalar transformPointCloud
+  if (!p) return NDT_E_ARG;
+  params_common(p);
+  p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 0;
+  return NDT_OK;
+}
+
+int ndt_params_pcl_new(ndt_params *p) {     // PCL >= 1.11: cov_ starts at zero, unbiased /(n-1)
+  if (!p) return NDT_E_ARG;
+  params_common(p);
+  p->cov_unbiased = 1; p->cov_init_identity = 0; p->transform_sse = 1;
+  return NDT_OK;
+}
+
+int ndt_default_params(ndt_params *p) { return ndt_params_pcl110(p); }
+
 const char *ndt_last_error(const ndt_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
 
-int ndt_ctx_create(int device, ndt_ctx **out) {
-  if (!out) return NDT_E_ARG;
-  *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
-    return fail(nullptr, NDT_E_NO_DEVICE, "no HIP device visible: libndt_mi355x has no CPU fallback");
-  if (device < 0 || device >= ndev) return fail(nullptr, NDT_E_ARG, "device ordinal out of range");
-  ndt_ctx *c = new (std::nothrow) ndt_ctx();
-  if (!c) return NDT_E_NOMEM;
+static int ctx_init(ndt_ctx *c, int device) {
   c->device = device;
   HIP_TRY(c, hipSetDevice(device));
   HIP_TRY(c, hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
@@ -234,27 +264,49 @@ int ndt_ctx_create(int device, ndt_ctx **out) {
   HIP_TRY(c, hipEventCreate(&c->evm1));
   HIP_TRY(c, hipEventCreateWithFlags(&c->evb, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
+  HIP_TRY(c, hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming));
   HIP_TRY(c, hipHostMalloc((void **)&c->h_bounds, 64, hipHostMallocDefault));
   { int rc = upload_exp_table(c); if (rc) return rc; }
-  {
-    hipDeviceProp_t prop;
-    HIP_TRY(c, hipGetDeviceProperties(&prop, device));
-    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
-    c->helpers = getenv("NDT_NO_HELPERS") ? 0 : kMaxHelpers;
-    if (getenv("NDT_MAX_HELPERS")) c->helpers = atoi(getenv("NDT_MAX_HELPERS"));
-    if (c->helpers > kMaxHelpers) c->helpers = kMaxHelpers;
-    if (c->helpers < 0) c->helpers = 0;
-    if (getenv("NDT_GRID")) c->num_cus = atoi(getenv("NDT_GRID"));
-  }
+  hipDeviceProp_t prop;
+  HIP_TRY(c, hipGetDeviceProperties(&prop, device));
+  c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+  c->helpers = kMaxHelpers;
+  return NDT_OK;
+}
+
+int ndt_ctx_create(int device, ndt_ctx **out) {
+  if (!out) return NDT_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, NDT_E_NO_DEVICE, "no HIP device visible: libndt_mi355x has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(nullptr, NDT_E_ARG, "device ordinal out of range");
+  ndt_ctx *c = new (std::nothrow) ndt_ctx();
+  if (!c) return NDT_E_NOMEM;
+  const int rc = ctx_init(c, device);
+  if (rc) { ndt_ctx_destroy(c); return rc; }      // (the error text stays in ndt_last_error(NULL))
   *out = c;
   return NDT_OK;
+}
+
+int ndt_ctx_set_option(ndt_ctx *c, int option, long long value) {
+  if (!c) return NDT_E_ARG;
+  switch (option) {
+    case NDT_OPT_MAX_HELPERS:
+      if (value < 0 || value > kMaxHelpers) return fail(c, NDT_E_ARG, "NDT_OPT_MAX_HELPERS: 0 .. 15");
+      c->helpers = (int)value; return NDT_OK;
+    case NDT_OPT_WORKGROUPS:
+      if (value < 0 || value > c->num_cus) return fail(c, NDT_E_ARG, "NDT_OPT_WORKGROUPS: 0 (one per CU) .. number of CUs");
+      c->workgroups = (int)value; return NDT_OK;
+    default: return fail(c, NDT_E_ARG, "ndt_ctx_set_option: unknown option");
+  }
 }
 
 int ndt_ctx_destroy(ndt_ctx *c) {
   if (!c) return NDT_E_ARG;
   hipError_t e;
   e = hipSetDevice(c->device);
-  e = hipStreamSynchronize(c->stream);
+  if (c->stream) e = hipStreamSynchronize(c->stream);
   if (c->own_stream) e = hipStreamDestroy(c->own_stream);
   if (c->ev0) e = hipEventDestroy(c->ev0);
   if (c->ev1) e = hipEventDestroy(c->ev1);
@@ -263,6 +315,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->evb) e = hipEventDestroy(c->evb);
   if (c->h_bounds) e = hipHostFree(c->h_bounds);
   if (c->ev_mm) e = hipEventDestroy(c->ev_mm);
+  if (c->ev_scratch) e = hipEventDestroy(c->ev_scratch);
   if (c->h_mm) e = hipHostFree(c->h_mm);
   void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
   for (void *b : bufs) if (b) e = hipFree(b);
@@ -372,24 +425,9 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   return NDT_OK;
 }
 
-int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, const ndt_params *prm,
-                      ndt_map **pmap) {
-  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
-  if (!xy || n == 0 || !prm || !pmap || !(prm->resolution > 0) || stride < 8 || (stride & 7))
-    return fail(ctx, NDT_E_ARG, "ndt_map_build: bad arguments (need n > 0, resolution > 0, stride % 8 == 0)");
-  if (n > (size_t)INT32_MAX) return fail(ctx, NDT_E_ARG, "ndt_map_build: more than 2^31 points");
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+// The build proper for an existing map object; any failure leaves the map without a speculative grid.
+static int map_build_impl(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size_t stride, const ndt_params *prm) {
   hipStream_t st = ctx->stream;
-  ndt_map *m = *pmap;
-  if (!m) {
-    m = new (std::nothrow) ndt_map();
-    if (!m) return NDT_E_NOMEM;
-    m->ctx = ctx;
-    HIP_TRY(ctx, hipMalloc(&m->bounds, 4 * sizeof(unsigned)));
-    HIP_TRY(ctx, hipMalloc(&m->counters, 4 * sizeof(int)));
-    HIP_TRY(ctx, hipMalloc(&m->total, sizeof(int)));
-    *pmap = m;
-  }
   m->prm = *prm; m->n = n; m->info_valid = false;
   HIP_TRY(ctx, hipEventRecord(ctx->evm0, st));
 
@@ -411,25 +449,54 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
     queued = true;
   }
   HIP_TRY(ctx, hipEventSynchronize(ctx->evb));
-  if (hb[0] == 0xffffffffu) { m->have_grid = false; return fail(ctx, NDT_E_ARG, "ndt_map_build: no finite points"); }
+  if (hb[0] == 0xffffffffu) return fail(ctx, NDT_E_ARG, "ndt_map_build: no finite points");
   const float mnx = ord2f(hb[0]), mny = ord2f(hb[1]), mxx = ord2f(hb[2]), mxy = ord2f(hb[3]);
   GridDims G;
   G.inv_leaf = inv_leaf;
   G.min_bx = (int)floorf(mnx * inv_leaf); G.min_by = (int)floorf(mny * inv_leaf);
   long long dx = (long long)(int)floorf(mxx * inv_leaf) - G.min_bx + 1;
   long long dy = (long long)(int)floorf(mxy * inv_leaf) - G.min_by + 1;
-  if (dx * dy > (1LL << 28)) { m->have_grid = false; return fail(ctx, NDT_E_GRID, "ndt_map_build: voxel grid larger than 2^28 cells"); }
+  if (dx * dy > (1LL << 28)) return fail(ctx, NDT_E_GRID, "ndt_map_build: voxel grid larger than 2^28 cells");
   G.div_x = (int)dx; G.div_y = (int)dy; G.gw = G.div_x + 4; G.gh = G.div_y + 4;
   const bool same = queued && G.min_bx == m->grid.min_bx && G.min_by == m->grid.min_by &&
                     G.div_x == m->grid.div_x && G.div_y == m->grid.div_y;
   if (!same) {
     int rc = queue_build(ctx, m, xy, n, stride, prm, G);
-    if (rc) { m->have_grid = false; return rc; }
+    if (rc) return rc;
   }
   m->grid = G; m->have_grid = true;
   HIP_TRY(ctx, hipEventRecord(ctx->evm1, st));
   ctx->map_ms_pending = true;
   return NDT_OK;                               // asynchronous from here on (stream order)
+}
+
+int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, const ndt_params *prm,
+                      ndt_map **pmap) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!xy || n == 0 || !prm || !pmap || !(prm->resolution > 0) || stride < 8 || (stride & 7))
+    return fail(ctx, NDT_E_ARG, "ndt_map_build: bad arguments (need n > 0, resolution > 0, stride % 8 == 0)");
+  if (n > (size_t)INT32_MAX) return fail(ctx, NDT_E_ARG, "ndt_map_build: more than 2^31 points");
+  if (*pmap && (*pmap)->ctx != ctx) return fail(ctx, NDT_E_ARG, "ndt_map_build: the map belongs to another context");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ndt_map *m = *pmap;
+  const bool fresh = (m == nullptr);
+  if (fresh) {
+    m = new (std::nothrow) ndt_map();
+    if (!m) return NDT_E_NOMEM;
+    m->ctx = ctx;
+    hipError_t e = hipMalloc(&m->bounds, 4 * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc(&m->counters, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc(&m->total, sizeof(int));
+    if (e != hipSuccess) { ndt_map_destroy(m); return fail(ctx, NDT_E_HIP, std::string("ndt_map_build: hipMalloc: ") + hipGetErrorString(e)); }
+  }
+  const int rc = map_build_impl(ctx, m, xy, n, stride, prm);
+  if (rc) {
+    m->have_grid = false;                      // a half-queued speculative build must not be trusted next time
+    if (fresh) ndt_map_destroy(m);             // (an existing map stays with its owner, unusable until rebuilt)
+    return rc;
+  }
+  *pmap = m;
+  return NDT_OK;
 }
 
 
@@ -508,25 +575,71 @@ int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, co
                         void *stream) {
   if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
   if (!map || !scans || !offsets || !inits || !out || B <= 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: bad arguments");
+  if (map->ctx->device != ctx->device) return fail(ctx, NDT_E_ARG, "ndt_align_batch: the map was built on another device");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   // the map build may still be running on the stream of the context that built the map
-  if (map->ctx && st != map->ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(st, map->ctx->evm1, 0));
+  if (st != map->ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(st, map->ctx->evm1, 0));
+  int rc;
+  if ((rc = scratch_begin(ctx, st))) return rc;
   float2 *sorted = nullptr;
   if (total_points > 0) {                      // shared scan: one slot of the scan's size per workgroup
-    int rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (shared_scan ? (size_t)ctx->num_cus : (size_t)1) * total_points * 8);
+    rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (shared_scan ? (size_t)ctx->num_cus : (size_t)1) * total_points * 8);
     if (rc) return rc;
     sorted = (float2 *)ctx->d_sorted;
   }
-  return launch_align(ctx, map, st, scans, (const unsigned long long *)offsets, B, shared_scan, inits, out,
-                      nullptr, 0, nullptr, sorted, nullptr);
+  if ((rc = launch_align(ctx, map, st, scans, (const unsigned long long *)offsets, B, shared_scan, inits, out,
+                         nullptr, 0, nullptr, sorted, nullptr)))
+    return rc;
+  return scratch_end(ctx, st);
 }
 
-int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, const uint64_t *offsets,
-                          int B, int shared_scan, const double *inits, ndt_result *out, double *trace,
-                          int trace_cap, int *trace_rows) {
+}  // extern "C"
+
+namespace {
+
+__global__ void __launch_bounds__(256)
+repack_f2_kernel(const float *__restrict__ in, size_t stride, size_t n, float2 *__restrict__ out) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    out[i] = load_pt(in, stride, i);
+}
+
+#ifdef NDT_DIAG
+// Diagnostic builds only (-DNDT_DIAG, tools/prof_phases.py): per-scan phase timers of the match kernel, printed
+// to stderr when NDT_PROF is set.  Release builds contain neither the environment look-up nor the report.
+void prof_report(const unsigned long long *hp, int B) {
+  double te = 0, ta = 0, tw = 0, ev = 0, sh = 0, hc = 0, worst = 0;
+  std::vector<unsigned long long> seen((size_t)B, 0ull);
+  for (int b = 0; b < B; ++b) {
+    te += hp[8 * b] * 0.01; ta += (hp[8 * b + 1] & 0xFFFFFFFFull) * 0.01; tw += hp[8 * b + 6] * 0.01;
+    ev += (double)(hp[8 * b + 3] & 0xFFFF); sh += (double)((hp[8 * b + 3] >> 16) & 0xFFFF); hc += (double)(hp[8 * b + 3] >> 32);
+    double tot = (hp[8 * b] + (hp[8 * b + 1] & 0xFFFFFFFFull)) * 0.01;
+    if (tot > worst) worst = tot;
+  }
+  for (int rep = 0; rep < 6 && rep < B; ++rep) {      // the longest scans
+    int best = -1; double bt = -1;
+    for (int b = 0; b < B; ++b) { double tot = (hp[8 * b] + (hp[8 * b + 1] & 0xFFFFFFFFull)) * 0.01; if (tot > bt && !seen[b]) { bt = tot; best = b; } }
+    if (best < 0) break;
+    fprintf(stderr, "[NDT_PROF]   scan %3d: %.0f us (fitness pass %.0f us, window spilled %d), passes %llu, shared %llu, helper units %llu, first shared pass at %.0f us (scan started %.0f, first helper attached %.0f, its window ready %.0f)\n", best, bt,
+            (double)((hp[8 * best + 1] >> 32) & 0x7FFFFFFFull) * 0.01, (int)(hp[8 * best + 1] >> 63),
+            hp[8 * best + 3] & 0xFFFF, (hp[8 * best + 3] >> 16) & 0xFFFF, (hp[8 * best + 3] >> 32) & 0x7FFFFFFF, (double)(hp[8 * best + 2] >> 32) * 0.01, (double)(hp[8 * best + 2] & 0xFFFFFFFFull) * 0.01,
+            (double)hp[8 * best + 4] * 0.01, (double)hp[8 * best + 5] * 0.01);
+    seen[best] = 1;
+  }
+  fprintf(stderr, "[NDT_PROF] B=%d passes=%.0f (+fitness) | per pass: compute+combine %.2f us, advance %.2f us | shared passes %.0f, helper chunks %.0f, owner wait %.2f us per shared pass | slowest scan %.1f us\n",
+          B, ev, te / (ev + B), ta / ev, sh, hc, sh > 0 ? tw / sh : 0.0, worst);
+  if (const char *dump = getenv("NDT_PROF_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(hp, 128, (size_t)B, f); fclose(f); } }
+}
+#endif
+
+// Host-pointer matches: stage scans (records of `stride` bytes, repacked to float2 on the device when stride != 8),
+// offsets and initial guesses, run the batch, copy the records back; synchronous.
+int align_host(ndt_ctx *ctx, const ndt_map *map, const float *scans, size_t stride, const uint64_t *offsets, int B,
+               int shared_scan, const double *inits, ndt_result *out, double *trace, int trace_cap, int *trace_rows) {
   if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
-  if (!map || !scans || !offsets || !inits || !out || B <= 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: bad arguments");
+  if (!map || !scans || !offsets || !inits || !out || B <= 0 || stride < 8 || (stride & 3))
+    return fail(ctx, NDT_E_ARG, "ndt_align_batch: bad arguments");
+  if (map->ctx->device != ctx->device) return fail(ctx, NDT_E_ARG, "ndt_align_batch: the map was built on another device");
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const size_t nscan = shared_scan ? 1 : (size_t)B;
@@ -535,7 +648,10 @@ int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, 
   for (size_t b = 0; b < nscan; ++b)
     if (offsets[b + 1] < offsets[b]) return fail(ctx, NDT_E_ARG, "ndt_align_batch: offsets not monotone");
   int rc;
-  if ((rc = ensure(ctx, &ctx->d_scan, &ctx->d_scan_cap, (size_t)offsets[nscan] * 8))) return rc;
+  if (st != map->ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(st, map->ctx->evm1, 0));
+  if ((rc = scratch_begin(ctx, st))) return rc;
+  const size_t ntot = (size_t)offsets[nscan];
+  if ((rc = ensure(ctx, &ctx->d_scan, &ctx->d_scan_cap, ntot * 8))) return rc;
   if ((rc = ensure(ctx, &ctx->d_off, &ctx->d_off_cap, (nscan + 1) * 8))) return rc;
   if ((rc = ensure(ctx, &ctx->d_init, &ctx->d_init_cap, (size_t)B * 24))) return rc;
   if ((rc = ensure(ctx, &ctx->d_res, &ctx->d_res_cap, (size_t)B * sizeof(ndt_result)))) return rc;
@@ -546,83 +662,69 @@ int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, 
     d_trace = (double *)ctx->d_trace; d_rows = (int *)ctx->d_rows;
     HIP_TRY(ctx, hipMemsetAsync(d_trace, 0, (size_t)B * trace_cap * 64, st));
   }
-  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scan, scans, (size_t)offsets[nscan] * 8, hipMemcpyHostToDevice, st));
+  if (stride == 8) {
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_scan, scans, ntot * 8, hipMemcpyHostToDevice, st));
+  } else {                                     // e.g. pcl::PointXYZ (16 bytes): strided upload, packed on the device
+    if ((rc = ensure(ctx, &ctx->d_tmp, &ctx->d_tmp_cap, ntot * stride))) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_tmp, scans, ntot * stride, hipMemcpyHostToDevice, st));
+    repack_f2_kernel<<<grid_for(ntot, 256), 256, 0, st>>>((const float *)ctx->d_tmp, stride, ntot, (float2 *)ctx->d_scan);
+  }
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_off, offsets, (nscan + 1) * 8, hipMemcpyHostToDevice, st));
   HIP_TRY(ctx, hipMemcpyAsync(ctx->d_init, inits, (size_t)B * 24, hipMemcpyHostToDevice, st));
-  // diagnostic phase timing (NDT_PROF=1): not part of the ABI, prints to stderr
   unsigned long long *d_prof = nullptr;
+#ifdef NDT_DIAG
   const bool want_prof = getenv("NDT_PROF") != nullptr;
   if (want_prof) { HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 128)); HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, (size_t)B * 128, st)); }
+#endif
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
-  float2 *sorted = nullptr;
-  if ((rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (shared_scan ? (size_t)ctx->num_cus : (size_t)1) * (size_t)offsets[nscan] * 8))) return rc;
-  sorted = (float2 *)ctx->d_sorted;
+  if ((rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (shared_scan ? (size_t)ctx->num_cus : (size_t)1) * ntot * 8))) return rc;
+  float2 *sorted = (float2 *)ctx->d_sorted;
   if ((rc = launch_align(ctx, map, st, (const float *)ctx->d_scan, (const unsigned long long *)ctx->d_off, B,
                          shared_scan, (const double *)ctx->d_init, (ndt_result *)ctx->d_res, d_trace, trace_cap,
                          d_rows, sorted, d_prof)))
     return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
+#ifdef NDT_DIAG
   if (want_prof) {
-    unsigned long long *hp = (unsigned long long *)malloc((size_t)B * 128);
+    std::vector<unsigned long long> hp((size_t)B * 16);
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    HIP_TRY(ctx, hipMemcpy(hp, d_prof, (size_t)B * 128, hipMemcpyDeviceToHost));
-    double te = 0, ta = 0, tw = 0, ev = 0, sh = 0, hc = 0, worst = 0;
-    for (int b = 0; b < B; ++b) {
-      te += hp[8 * b] * 0.01; ta += (hp[8 * b + 1] & 0xFFFFFFFFull) * 0.01; tw += hp[8 * b + 6] * 0.01;
-      ev += (double)(hp[8 * b + 3] & 0xFFFF); sh += (double)((hp[8 * b + 3] >> 16) & 0xFFFF); hc += (double)(hp[8 * b + 3] >> 32);
-      double tot = (hp[8 * b] + (hp[8 * b + 1] & 0xFFFFFFFFull)) * 0.01;
-      if (tot > worst) worst = tot;
-    }
-    for (int rep = 0; rep < 6 && rep < B; ++rep) {      // the longest scans
-      int best = -1; double bt = -1;
-      for (int b = 0; b < B; ++b) { double tot = (hp[8 * b] + (hp[8 * b + 1] & 0xFFFFFFFFull)) * 0.01; if (tot > bt && !(hp[8 * b + 3] >> 63)) { bt = tot; best = b; } }
-      if (best < 0) break;
-      fprintf(stderr, "[NDT_PROF]   scan %3d: %.0f us (fitness pass %.0f us, window spilled %d), passes %llu, shared %llu, helper units %llu, first shared pass at %.0f us (scan started %.0f, first helper attached %.0f, its window ready %.0f)\n", best, bt,
-              (double)((hp[8 * best + 1] >> 32) & 0x7FFFFFFFull) * 0.01, (int)(hp[8 * best + 1] >> 63),
-              hp[8 * best + 3] & 0xFFFF, (hp[8 * best + 3] >> 16) & 0xFFFF, (hp[8 * best + 3] >> 32) & 0x7FFFFFFF, (double)(hp[8 * best + 2] >> 32) * 0.01, (double)(hp[8 * best + 2] & 0xFFFFFFFFull) * 0.01,
-              (double)hp[8 * best + 4] * 0.01, (double)hp[8 * best + 5] * 0.01);
-      hp[8 * best + 3] |= 1ull << 63;
-    }
-    fprintf(stderr, "[NDT_PROF] B=%d passes=%.0f (+fitness) | per pass: compute+combine %.2f us, advance %.2f us | shared passes %.0f, helper chunks %.0f, owner wait %.2f us per shared pass | slowest scan %.1f us\n",
-            B, ev, te / (ev + B), ta / ev, sh, hc, sh > 0 ? tw / sh : 0.0, worst);
-    if (const char *dump = getenv("NDT_PROF_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(hp, 128, (size_t)B, f); fclose(f); } }
-    free(hp);
+    HIP_TRY(ctx, hipMemcpy(hp.data(), d_prof, (size_t)B * 128, hipMemcpyDeviceToHost));
+    prof_report(hp.data(), B);
     hipError_t e = hipFree(d_prof); (void)e;
   }
+#endif
   HIP_TRY(ctx, hipMemcpyAsync(out, ctx->d_res, (size_t)B * sizeof(ndt_result), hipMemcpyDeviceToHost, st));
   if (d_trace) {
     HIP_TRY(ctx, hipMemcpyAsync(trace, d_trace, (size_t)B * trace_cap * 64, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(trace_rows, d_rows, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   }
+  if ((rc = scratch_end(ctx, st))) return rc;
   HIP_TRY(ctx, hipStreamSynchronize(st));
   HIP_TRY(ctx, hipEventElapsedTime(&ctx->align_ms, ctx->ev0, ctx->ev1));
   return NDT_OK;
 }
 
+}  // namespace
+
+extern "C" {
+
+int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, const uint64_t *offsets,
+                          int B, int shared_scan, const double *inits, ndt_result *out, double *trace,
+                          int trace_cap, int *trace_rows) {
+  return align_host(ctx, map, scans, 8, offsets, B, shared_scan, inits, out, trace, trace_cap, trace_rows);
+}
+
 int ndt_align_batch(ndt_ctx *ctx, const ndt_map *map, const float *scans, const uint64_t *offsets, int B,
                     int shared_scan, const double *inits, ndt_result *out) {
-  return ndt_align_batch_trace(ctx, map, scans, offsets, B, shared_scan, inits, out, nullptr, 0, nullptr);
+  return align_host(ctx, map, scans, 8, offsets, B, shared_scan, inits, out, nullptr, 0, nullptr);
 }
 
 int ndt_align(ndt_ctx *ctx, const ndt_map *map, const float *scan, size_t n, size_t stride,
               const double init[3], ndt_result *out) {
   if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
-  if (!map || !scan || n == 0 || !init || !out || stride < 8) return fail(ctx, NDT_E_ARG, "ndt_align: bad arguments");
-  const float *packed = scan;
-  float *tmp = nullptr;
-  if (stride != 8) {   // repack pcl::PointXYZ-style records to float2
-    tmp = (float *)malloc(n * 8);
-    if (!tmp) return NDT_E_NOMEM;
-    for (size_t i = 0; i < n; ++i) {
-      const float *p = (const float *)((const char *)scan + i * stride);
-      tmp[2 * i] = p[0]; tmp[2 * i + 1] = p[1];
-    }
-    packed = tmp;
-  }
-  uint64_t off[2] = {0, (uint64_t)n};
-  int rc = ndt_align_batch(ctx, map, packed, off, 1, 0, init, out);
-  free(tmp);
-  return rc;
+  if (!map || !scan || n == 0 || !init || !out || stride < 8 || (stride & 3)) return fail(ctx, NDT_E_ARG, "ndt_align: bad arguments");
+  const uint64_t off[2] = {0, (uint64_t)n};
+  return align_host(ctx, map, scan, stride, off, 1, 0, init, out, nullptr, 0, nullptr);
 }
 
 int ndt_eval_at(ndt_ctx *ctx, const ndt_map *map, const float *scan, size_t n, size_t stride,
@@ -701,6 +803,7 @@ int ndt_prefilter_batch_dev(ndt_ctx *ctx, const float *raw_xy, size_t stride, co
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   int rc;
+  if ((rc = scratch_begin(ctx, st))) return rc;
   // filtered points at the raw offsets, then the per-scan counts
   const size_t tmp_bytes = total_raw_points * sizeof(float2);
   if ((rc = ensure(ctx, &ctx->d_pf, &ctx->d_pf_cap, 2 * tmp_bytes + (size_t)B * sizeof(unsigned)))) return rc;
@@ -708,17 +811,14 @@ int ndt_prefilter_batch_dev(ndt_ctx *ctx, const float *raw_xy, size_t stride, co
   float2 *sparse = (float2 *)((char *)ctx->d_pf + tmp_bytes);          // flushes at the index of their cause
   unsigned *counts = (unsigned *)((char *)ctx->d_pf + 2 * tmp_bytes);
   const int grid = B < 8 * ctx->num_cus ? B : 8 * ctx->num_cus;
-  if (getenv("NDT_PREFILTER_1WAVE"))     // diagnostic: the one-wave-per-scan kernel
-    prefilter_kernel<<<grid, 64, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf, tmp, counts);
-  else
-    prefilter_mw_kernel<<<grid, 64 * kPfWaves, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf,
-                                                        sparse, tmp, counts);
+  prefilter_mw_kernel<<<grid, 64 * kPfWaves, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf,
+                                                      sparse, tmp, counts);
   prefilter_offsets_kernel<<<1, 1024, 0, st>>>(counts, B, (unsigned long long *)out_offsets);
   const int gx = (int)std::min<size_t>(64, (total_raw_points / (size_t)B + 255) / 256 + 1);
   prefilter_pack_kernel<<<dim3((unsigned)gx, (unsigned)std::min(B, 65535)), 256, 0, st>>>(
       tmp, (const unsigned long long *)raw_offsets, (const unsigned long long *)out_offsets, B, (float2 *)out_xy);
   HIP_TRY(ctx, hipGetLastError());
-  return NDT_OK;
+  return scratch_end(ctx, st);
 }
 
 int ndt_prefilter(ndt_ctx *ctx, const float *xy_host, size_t n, size_t stride, float leaf, float *out_xy_host,
@@ -792,6 +892,7 @@ int ndt_remove_neighbors_dev(ndt_ctx *ctx, const float *base_xy, size_t base_str
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   const int nblocks = (int)((n_base + kRnBlock - 1) / kRnBlock);
   int rc;
+  if ((rc = scratch_begin(ctx, st))) return rc;
   if ((rc = ensure(ctx, &ctx->d_rn, &ctx->d_rn_cap, n_base + (size_t)nblocks * sizeof(int) + 16))) return rc;
   int *block_count = (int *)ctx->d_rn;
   unsigned char *keep = (unsigned char *)ctx->d_rn + (size_t)nblocks * sizeof(int);
@@ -801,7 +902,7 @@ int ndt_remove_neighbors_dev(ndt_ctx *ctx, const float *base_xy, size_t base_str
   remove_neighbors_pack_kernel<<<nblocks, kRnBlock, 0, st>>>(base_xy, base_stride, (int)n_base, keep, block_count,
                                                              (float2 *)out_xy);
   HIP_TRY(ctx, hipGetLastError());
-  return NDT_OK;
+  return scratch_end(ctx, st);
 }
 
 int ndt_remove_neighbors(ndt_ctx *ctx, const float *base_xy_host, size_t base_stride, size_t n_base,
@@ -869,6 +970,7 @@ int mm_prepare(ndt_ctx *ctx, const MmPlan &P, float2 *diff_override, hipStream_t
   L.o_diff = L.o_tab + tab_words * 8;
   const size_t total = L.o_diff + list_pts * 8 + 64;
   int rc;
+  if ((rc = scratch_begin(ctx, st))) return rc;
   if ((rc = ensure(ctx, &ctx->d_mm, &ctx->d_mm_cap, total))) return rc;
   if (ctx->mm_pending) { HIP_TRY(ctx, hipEventSynchronize(ctx->ev_mm)); ctx->mm_pending = false; }
   if (L.o_ucnt > ctx->h_mm_cap) {
@@ -920,7 +1022,7 @@ int mm_run(ndt_ctx *ctx, const MmLayout &L, size_t nj, size_t nu, double resol, 
                                                           (float2 *)out_xy);
   }
   HIP_TRY(ctx, hipGetLastError());
-  return NDT_OK;
+  return scratch_end(ctx, st);
 }
 
 }  // namespace

@@ -27,7 +27,8 @@ class Cells:
     """Voxel normal distributions (a2).  Dense grid -> compact table in ascending index order."""
 
     def __init__(self, map_xy, resolution, min_pts=6, eig_mult=0.01, unbiased=False,
-                 init_identity=False):
+                 init_identity=True):
+        # defaults = PCL 1.10: Leaf() starts the sum of products at the identity, (n-1)/n normalisation
         xy = np.ascontiguousarray(map_xy, dtype=F)
         self.res = F(resolution)
         self.inv = F(1.0) / self.res
@@ -110,7 +111,7 @@ class Cells:
         return np.array(pi, dtype=np.int64), np.array(ci, dtype=np.int64)
 
 
-def transform32(scan32, p, sse=False):
+def transform32(scan32, p, sse=True):
     """x' = R(yaw) x + t in float32 with the float32 matrix of the fp64 parameters (a4)."""
     yaw = F(p[2])
     c = F(math.cos(float(yaw))); s = F(math.sin(float(yaw)))
@@ -227,12 +228,12 @@ def yaw_from_T(T00, T10):
 
 
 def align(cells, scan32, init, resolution, step_size=0.1, trans_eps=0.01, max_iter=35,
-          outlier_ratio=0.55, stale_h_ang=True, mu=1e-4, nu=0.9, mt_max=10):
+          outlier_ratio=0.55, stale_h_ang=True, mu=1e-4, nu=0.9, mt_max=10, sse=True):
     """Newton + More-Thuente driver (Magnusson Algorithm 2 with PCL's step clamp)."""
     d1, d2 = gauss_constants(resolution, outlier_ratio)
     scan32 = np.ascontiguousarray(scan32, dtype=F)
     log = []
-    trans, T = transform32(scan32, init)
+    trans, T = transform32(scan32, init, sse)
     p = np.array([float(T[2]), float(T[3]), float(F(math.atan2(float(T[1]), float(T[0]))))])
     state = {"yaw_h": p[2], "evals": 0}
 
@@ -264,7 +265,7 @@ def align(cells, scan32, init, resolution, step_size=0.1, trans_eps=0.01, max_it
             open_iv, done, k = True, (step_size - trans_eps / 2) < 0, 0
             a = max(min(nrm, step_size), trans_eps / 2)
             xt = p + d * a
-            trans, T = transform32(scan32, xt)
+            trans, T = transform32(scan32, xt, sse)
             score, g, H, _ = derivs(xt, trans, True)
             log.append((a, score))
             phit, dphit = -score, -float(g @ d)
@@ -274,7 +275,7 @@ def align(cells, scan32, init, resolution, step_size=0.1, trans_eps=0.01, max_it
                 a = a if not (step_size < a) else step_size
                 a = a if not (a < trans_eps / 2) else trans_eps / 2
                 xt = p + d * a
-                trans, T = transform32(scan32, xt)
+                trans, T = transform32(scan32, xt, sse)
                 score, g, _, _ = derivs(xt, trans, False)
                 log.append((a, score))
                 phit, dphit = -score, -float(g @ d)
@@ -299,12 +300,16 @@ def align(cells, scan32, init, resolution, step_size=0.1, trans_eps=0.01, max_it
                 pose=np.array([float(T[2]), float(T[3]), yaw_from_T(T[0], T[1])]))
 
 
-def fitness(map_xy, scan32, T):
+def fitness(map_xy, scan32, T, sse=True):
     """Mean float32 squared distance to the nearest raw map point (a7), brute force."""
     c, s, tx, ty = T
     x = scan32[:, 0].astype(F); y = scan32[:, 1].astype(F)
-    qx = F(F(c * x) + F(-s * y)) + tx
-    qy = F(F(s * x) + F(c * y)) + ty
+    if not sse:
+        qx = F(F(c * x) + F(-s * y)) + tx
+        qy = F(F(s * x) + F(c * y)) + ty
+    else:
+        qx = F(c * x) + F(F(-s * y) + tx)
+        qy = F(s * x) + F(F(c * y) + ty)
     m = np.ascontiguousarray(map_xy, dtype=F)
     tot = 0.0
     for i in range(len(qx)):

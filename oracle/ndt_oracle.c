@@ -25,9 +25,9 @@
 /* parameters                                                                                  */
 /* ------------------------------------------------------------------------------------------ */
 
-/* Defaults: PoseEstimator.h:63-64 constructor values overridden by ndt_mapping.launch:32-36
- * are set by the caller; here the PCL-side defaults. */
-void ndt_oracle_default_params(ndt_oracle_params *p) {
+/* PoseEstimator.h:63-64 constructor values (overridden by ndt_mapping.launch:32-36 in the caller) and
+ * the PCL-side defaults every version shares. */
+static void params_common(ndt_oracle_params *p) {
   memset(p, 0, sizeof(*p));
   p->resolution = 1.0f;   /* PoseEstimator.h:64 */
   p->step_size = 0.1;     /* PoseEstimator.h:64 */
@@ -36,17 +36,27 @@ void ndt_oracle_default_params(ndt_oracle_params *p) {
   p->outlier_ratio = 0.55;
   p->min_pts = 6;
   p->eig_mult = 0.01;
-  p->cov_unbiased = 0;
-  p->cov_init_identity = 0;
   p->conv_ge = 0;
   p->radius_inclusive = 0;
-  p->transform_sse = 0;
   p->stale_h_ang = 1;
   p->snap_thresh = 10e-5;
   p->mt_max_iter = 10;
   p->mt_mu = 1.e-4;
   p->mt_nu = 0.9;
 }
+
+/* Presets of the version-sensitive switches.  preset 0 = PCL 1.9/1.10 (the default: the
+ * reference only compiles against PCL <= 1.10, PoseEstimator.h:72-73): VoxelGridCovariance::Leaf() starts
+ * cov_ at the identity, (n-1)/n normalisation, SSE transformPointCloud; 1 = PCL <= 1.8: the same with the
+ * scalar transformPointCloud; 2 = PCL >= 1.11: cov_ starts at zero, /(n-1). */
+void ndt_oracle_params_preset(ndt_oracle_params *p, int preset) {
+  params_common(p);
+  if (preset == 2) { p->cov_unbiased = 1; p->cov_init_identity = 0; p->transform_sse = 1; }
+  else if (preset == 1) { p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 0; }
+  else { p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 1; }
+}
+
+void ndt_oracle_default_params(ndt_oracle_params *p) { ndt_oracle_params_preset(p, 0); }
 
 /* a3: Gaussian fitting constants, Magnusson 2009 eq 6.8, recomputed at the top of
  * computeTransformation (called from src/PoseEstimator.cpp:28 ndt.align). */
@@ -727,7 +737,7 @@ int ndt_oracle_align(const ndt_oracle_map *m, const float *scan, size_t n, size_
   res->H[0] = H8[0]; res->H[1] = res->H[3] = H8[1]; res->H[2] = res->H[6] = H8[2];
   res->H[4] = H8[3]; res->H[5] = res->H[7] = H8[4]; res->H[8] = H8[5];
   res->evals = cx.evals; res->ref_evals = cx.ref_evals;
-  res->pad_ = cx.trace_n;   /* number of trace rows (derivative passes with a gradient) */
+  res->flags = cx.trace_n;   /* number of trace rows (derivative passes with a gradient) */
   res->kbar = cx.pairs / ((double)cx.evals * (double)n);
   res->status = 0;
   free(cx.trans);
@@ -744,6 +754,22 @@ int ndt_oracle_align_batch(const ndt_oracle_map *m, const float *scans, const ui
   for (int b = 0; b < B; ++b) {
     int r = ndt_oracle_align(m, scans + 2 * off[b], (size_t)(off[b + 1] - off[b]), 2 * sizeof(float),
                              inits + 3 * b, &res[b], NULL, 0);
+    if (r) rc = r;
+  }
+  (void)nthreads;
+  return rc;
+}
+
+/* BASELINE.json configs[4]: B initial guesses for ONE scan (multi-hypothesis relocalisation). */
+int ndt_oracle_align_seeds(const ndt_oracle_map *m, const float *scan, size_t n, int B,
+                           const double *inits, ndt_oracle_result *res, int nthreads) {
+  int rc = 0;
+#ifdef _OPENMP
+  if (nthreads > 1) omp_set_num_threads(nthreads);
+#pragma omp parallel for schedule(dynamic, 1) if (nthreads > 1)
+#endif
+  for (int b = 0; b < B; ++b) {
+    int r = ndt_oracle_align(m, scan, n, 2 * sizeof(float), inits + 3 * b, &res[b], NULL, 0);
     if (r) rc = r;
   }
   (void)nthreads;

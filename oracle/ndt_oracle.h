@@ -41,7 +41,7 @@ typedef struct ndt_oracle_params {
   double outlier_ratio;     /* PCL default 0.55                                               */
   int    min_pts;           /* VoxelGridCovariance min_points_per_voxel_ = 6                  */
   double eig_mult;          /* VoxelGridCovariance min_covar_eigvalue_mult_ = 0.01            */
-  /* ---- version-sensitive switches; defaults = PCL <= 1.10 as surveyed ---- */
+  /* ---- version-sensitive switches; defaults = PCL 1.10 (ndt_oracle_params_preset 0) ---- */
   int    cov_unbiased;      /* (1) 0: (Sxx/n - mu mu^T)(n-1)/n   1: /(n-1)                     */
   int    cov_init_identity; /* (1b) 1: per-voxel Sxx accumulator starts at I (old PCL Leaf())  */
   int    conv_ge;           /* (2) 0: stop when iter > max_iter  1: iter >= max_iter           */
@@ -73,13 +73,16 @@ typedef struct ndt_oracle_result {
                          passes and the a8 getHessian pass)                                      */
   int    converged;   /* hasConverged()                                                          */
   int    status;      /* 0 ok; <0 error                                                          */
-  int    pad_;
+  int    flags;   /* product: data-path bits (NDT_FLAG_*); the oracle has one path and returns the number of trace rows here */
   double kbar;        /* mean in-radius cells per point-evaluation                               */
 } ndt_oracle_result;
 
 typedef struct ndt_oracle_map ndt_oracle_map;
 
-void ndt_oracle_default_params(ndt_oracle_params *p);
+void ndt_oracle_default_params(ndt_oracle_params *p);          /* = preset 0 */
+/* 0: PCL 1.9/1.10 (identity-initialised cov_, (n-1)/n, SSE transform); 1: PCL <= 1.8 (scalar transform);
+ * 2: PCL >= 1.11 (zero-initialised cov_, /(n-1)) */
+void ndt_oracle_params_preset(ndt_oracle_params *p, int preset);
 
 /* a2: VoxelGridCovariance::filter(true) over a z=0 cloud.  xy points at byte stride. */
 ndt_oracle_map *ndt_oracle_map_build(const float *xy, size_t n, size_t stride_bytes,
@@ -118,6 +121,9 @@ int ndt_oracle_align(const ndt_oracle_map *m, const float *scan_xy, size_t n, si
 int ndt_oracle_align_batch(const ndt_oracle_map *m, const float *scans_xy,
                            const uint64_t *offsets, int B, const double *inits,
                            ndt_oracle_result *res, int nthreads);
+/* the same scan from B initial guesses (BASELINE.json configs[4]) */
+int ndt_oracle_align_seeds(const ndt_oracle_map *m, const float *scan_xy, size_t n, int B,
+                           const double *inits, ndt_oracle_result *res, int nthreads);
 
 /* a7 alone at an explicit float32 matrix (c, s, tx, ty). */
 double ndt_oracle_fitness(const ndt_oracle_map *m, const float *scan_xy, size_t n,

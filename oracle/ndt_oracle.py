@@ -31,7 +31,7 @@ class Result(C.Structure):
         ("T13", C.c_float), ("fitness", C.c_double), ("trans_prob", C.c_double),
         ("score", C.c_double), ("H", C.c_double * 9), ("p", C.c_double * 3), ("iters", C.c_int),
         ("evals", C.c_int), ("ref_evals", C.c_int), ("converged", C.c_int), ("status", C.c_int),
-        ("pad_", C.c_int), ("kbar", C.c_double),
+        ("flags", C.c_int), ("kbar", C.c_double),
     ]
 
 
@@ -44,7 +44,7 @@ RESULT_DTYPE = np.dtype([
     ("pose", "f8", 3), ("T00", "f4"), ("T10", "f4"), ("T03", "f4"), ("T13", "f4"),
     ("fitness", "f8"), ("trans_prob", "f8"), ("score", "f8"), ("H", "f8", 9), ("p", "f8", 3),
     ("iters", "i4"), ("evals", "i4"), ("ref_evals", "i4"), ("converged", "i4"), ("status", "i4"),
-    ("pad_", "i4"), ("kbar", "f8")], align=True)
+    ("flags", "i4"), ("kbar", "f8")], align=True)
 assert RESULT_DTYPE.itemsize == C.sizeof(Result)
 
 
@@ -66,6 +66,7 @@ def lib():
     L = C.CDLL(so)
     vp, sz, dp, fp = C.c_void_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_float)
     L.ndt_oracle_default_params.argtypes = [C.POINTER(Params)]
+    L.ndt_oracle_params_preset.argtypes = [C.POINTER(Params), C.c_int]
     L.ndt_oracle_map_build.restype = vp
     L.ndt_oracle_map_build.argtypes = [vp, sz, sz, C.POINTER(Params)]
     L.ndt_oracle_map_destroy.argtypes = [vp]
@@ -77,6 +78,8 @@ def lib():
     L.ndt_oracle_align.argtypes = [vp, vp, sz, sz, dp, C.POINTER(Result), vp, C.c_int]
     L.ndt_oracle_align_batch.restype = C.c_int
     L.ndt_oracle_align_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int]
+    L.ndt_oracle_align_seeds.restype = C.c_int
+    L.ndt_oracle_align_seeds.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, C.c_int]
     L.ndt_oracle_fitness.restype = C.c_double
     L.ndt_oracle_fitness.argtypes = [vp, vp, sz, sz, C.c_float, C.c_float, C.c_float, C.c_float]
     L.ndt_oracle_approx_voxel_filter.restype = sz
@@ -93,9 +96,12 @@ def lib():
     return L
 
 
-def default_params(**kw):
+PRESETS = {"default": 0, "pcl110": 0, "pcl18": 1, "pcl_new": 2}
+
+
+def default_params(preset="default", **kw):
     p = Params()
-    lib().ndt_oracle_default_params(C.byref(p))
+    lib().ndt_oracle_params_preset(C.byref(p), PRESETS[preset])
     for k, v in kw.items():
         setattr(p, k, v)
     return p
@@ -150,13 +156,19 @@ class Map:
                                C.byref(r), tr.ctypes.data if trace_cap else None, trace_cap)
         out = np.frombuffer(bytes(r), dtype=RESULT_DTYPE)[0].copy()
         if trace_cap:
-            return out, tr[:min(trace_cap, int(out["pad_"]))]
+            return out, tr[:min(trace_cap, int(out["flags"]))]
         return out
 
-    def align_batch(self, scans, offsets, inits, nthreads=1):
+    def align_batch(self, scans, offsets, inits, nthreads=1, shared_scan=False):
         scans = _f32c(scans)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
-        inits = np.ascontiguousarray(inits, dtype=np.float64)
+        inits = np.ascontiguousarray(inits, dtype=np.float64).reshape(-1, 3)
+        if shared_scan:                       # every initial guess against scan 0
+            B = len(inits)
+            res = np.zeros(B, dtype=RESULT_DTYPE)
+            one = scans[int(offsets[0]):int(offsets[1])]
+            lib().ndt_oracle_align_seeds(self.h, one.ctypes.data, len(one), B, inits.ctypes.data, res.ctypes.data, nthreads)
+            return res
         B = len(offsets) - 1
         res = np.zeros(B, dtype=RESULT_DTYPE)
         lib().ndt_oracle_align_batch(self.h, scans.ctypes.data, offsets.ctypes.data, B,

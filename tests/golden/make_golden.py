@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Generates tests/golden/c1_golden.npz.
+"""Generates tests/golden/c1_golden.npz (default preset = PCL 1.10 semantics) and
+tests/golden/c1_golden_pcl_new.npz (the PCL >= 1.11 preset: zero-initialised, unbiased voxel covariance).
 
 The reference ships no golden vectors, and its hot path (PCL) cannot be built
 or imported here, so these vectors come from this repo's CPU restatement (oracle/ndt_oracle.c,
@@ -20,12 +21,12 @@ from ndt_slam_amd import synth          # noqa: E402
 from oracle import ndt_oracle as O      # noqa: E402
 
 
-def main():
+def main(preset="default", name="c1_golden.npz"):
     cfg = synth.CONFIGS["C1"]
     m = synth.make_map(cfg["n_map"], cfg["half"])
     sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
     scans, off, truths, inits = sf.batch(0, 8)
-    M = O.Map(m, O.default_params(resolution=cfg["resolution"]))
+    M = O.Map(m, O.default_params(preset, resolution=cfg["resolution"]))
     res = M.align_batch(scans, off, inits)
     _, trace0 = M.align(scans[int(off[0]):int(off[1])], inits[0], trace_cap=256)
     t = M.export()
@@ -36,14 +37,15 @@ def main():
         s, g, H, pairs = M.eval_at(sc, inits[b])
         evals.append(np.concatenate([[s], g, H.ravel(), [pairs]]))
     filt = O.approx_voxel_filter(scans[int(off[0]):int(off[1])], 0.05)
-    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c1_golden.npz")
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), name)
     np.savez_compressed(
         out, map_xy=m, scans=scans, offsets=off, truths=truths, inits=inits, results=res,
         trace0=trace0, cell_idx=t["idx"], cell_cent=t["cent"], cell_mean=t["mean"], cell_icov=t["icov"],
         cell_npts=t["npts"], grid=np.array([info.min_bx, info.min_by, info.div_x, info.div_y, info.n_cells, info.n_valid]),
-        evals=np.stack(evals), filtered0=filt, resolution=np.float32(cfg["resolution"]))
+        evals=np.stack(evals), filtered0=filt, resolution=np.float32(cfg["resolution"]), preset=np.array(preset))
     print("wrote", out, os.path.getsize(out), "bytes")
 
 
 if __name__ == "__main__":
     main()
+    main("pcl_new", "c1_golden_pcl_new.npz")

@@ -7,12 +7,17 @@ import os
 import numpy as np
 import pytest
 
-GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c1_golden.npz")
+GOLD_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.fixture(scope="module")
-def gold():
-    return np.load(GOLD)
+@pytest.fixture(scope="module", params=["c1_golden.npz", "c1_golden_pcl_new.npz"])
+def gold(request):
+    """Two files: the default preset (PCL 1.10 semantics) and the PCL >= 1.11 preset."""
+    return np.load(os.path.join(GOLD_DIR, request.param))
+
+
+def _preset(gold):
+    return str(gold["preset"])
 
 
 def check_results(res, gold_res, exact_counts=True):
@@ -41,7 +46,7 @@ def test_generator_is_stable(gold):
 
 
 def test_oracle_reproduces_golden(oracle, gold):
-    M = oracle.Map(gold["map_xy"], oracle.default_params(resolution=float(gold["resolution"])))
+    M = oracle.Map(gold["map_xy"], oracle.default_params(_preset(gold), resolution=float(gold["resolution"])))
     i = M.info()
     assert [i.min_bx, i.min_by, i.div_x, i.div_y, i.n_cells, i.n_valid] == gold["grid"].tolist()
     t = M.export()
@@ -66,7 +71,7 @@ def test_oracle_reproduces_golden(oracle, gold):
 def test_hip_path_matches_golden(gold):
     from ndt_slam_amd import capi
     ctx = capi.Context(0)
-    gm = capi.Map(ctx, gold["map_xy"], capi.default_params(resolution=float(gold["resolution"])))
+    gm = capi.Map(ctx, gold["map_xy"], capi.default_params(_preset(gold), resolution=float(gold["resolution"])))
     t = gm.export()
     assert np.array_equal(t["idx"], gold["cell_idx"]) and np.array_equal(t["cent"], gold["cell_cent"])
     assert np.array_equal(t["mean"], gold["cell_mean"])

@@ -95,7 +95,7 @@ def test_solve3_matches_lstsq_and_pinv(oracle):
 def test_voxel_statistics_hand_case(oracle):
     # six points in one 1 m voxel + a sparse voxel that must be dropped (min_pts = 6)
     pts = np.array([[0.1, 0.2], [0.3, 0.25], [0.5, 0.2], [0.7, 0.3], [0.9, 0.2], [0.5, 0.6], [3.5, 3.5]], np.float32)
-    M = oracle.Map(pts, oracle.default_params(resolution=1.0))
+    M = oracle.Map(pts, oracle.default_params(resolution=1.0, cov_init_identity=0))
     t = M.export()
     assert M.info().n_cells == 1 and t["npts"][0] == 6
     p = pts[:6].astype(np.float64)
@@ -110,24 +110,78 @@ def test_voxel_statistics_hand_case(oracle):
     assert np.array_equal(t["cent"][0], c32)
 
 
+def _leaf_identity_by_hand(p, eig_mult=0.01):
+    """PCL <= 1.10 voxel statistics written out in 3-D: Leaf() starts cov_ at the identity, applyFilter adds
+    pt pt^T on top and normalises with the single-pass formula and (n-1)/n."""
+    n = len(p)
+    p3 = np.column_stack([p, np.zeros(n)])
+    S = np.eye(3) + p3.T @ p3
+    pt_sum = p3.sum(0)
+    mu = pt_sum / n
+    cov = (S - 2 * np.outer(pt_sum, mu)) / n + np.outer(mu, mu)
+    cov *= (n - 1.0) / n
+    w, V = np.linalg.eigh(cov)
+    if w[0] < eig_mult * w[2]:
+        w[0] = eig_mult * w[2]
+        if w[1] < eig_mult * w[2]:
+            w[1] = eig_mult * w[2]
+        cov = V @ np.diag(w) @ np.linalg.inv(V)
+    return mu[:2], np.linalg.inv(cov)[:2, :2], w, V
+
+
+def test_voxel_statistics_identity_default(oracle):
+    """Default preset (PCL 1.10): the identity start adds (n-1)/n^2 to every diagonal entry of the covariance;
+    the z eigenvalue (n-1)/n^2 takes part in the ascending sort and in the 0.01 * max inflation floor."""
+    pts = np.array([[0.1, 0.2], [0.3, 0.25], [0.5, 0.2], [0.7, 0.3], [0.9, 0.2], [0.5, 0.6]], np.float32)
+    prm = oracle.default_params(resolution=1.0)
+    assert prm.cov_init_identity == 1 and prm.cov_unbiased == 0
+    t = oracle.Map(pts, prm).export()
+    mu, icov, w, V = _leaf_identity_by_hand(pts.astype(np.float64))
+    assert t["mean"][0] == pytest.approx(mu, rel=1e-14)
+    assert t["icov"][0] == pytest.approx([icov[0, 0], icov[0, 1], icov[1, 1]], rel=1e-10)
+    # a short, nearly collinear run of 7 points: without the identity its minor variance would be inflated to
+    # 1 % of the major one; with it both are czz = 6/49 plus the spread, i.e. a nearly isotropic, fat Gaussian
+    x = np.linspace(0.45, 0.55, 7)
+    line = np.stack([x, 0.5 + 1e-5 * np.sin(37 * x)], 1).astype(np.float32)
+    t = oracle.Map(line, prm).export()
+    mu, icov, w, V = _leaf_identity_by_hand(line.astype(np.float64))
+    czz = 6.0 / 49.0
+    assert w[0] == pytest.approx(czz, rel=1e-12) and abs(V[2, 0]) == pytest.approx(1.0)   # the z pair sorts first
+    ic = np.array([[t["icov"][0][0], t["icov"][0][1]], [t["icov"][0][1], t["icov"][0][2]]])
+    ev = np.linalg.eigvalsh(np.linalg.inv(ic))
+    assert ev[0] == pytest.approx(czz, rel=1e-3) and ev[1] == pytest.approx(czz + np.var(x) * 6 / 7, rel=1e-3)
+    assert t["icov"][0] == pytest.approx([icov[0, 0], icov[0, 1], icov[1, 1]], rel=1e-9)
+    # a long wall through a 4 m voxel with many points: (n-1)/n^2 = 0.005 is below the major variance, and the
+    # minor one (wall noise + 0.005) is lifted to the 1 % floor set by the MAJOR axis -- the usual inflation
+    rng = np.random.default_rng(3)
+    wall = np.stack([np.linspace(0.1, 3.9, 200), 2.0 + rng.normal(0, 0.002, 200)], 1).astype(np.float32)
+    t = oracle.Map(wall, oracle.default_params(resolution=4.0)).export()
+    mu, icov, w, V = _leaf_identity_by_hand(wall.astype(np.float64))
+    assert abs(V[2, 0]) == pytest.approx(1.0) and w[2] > 1.0 and w[1] == pytest.approx(0.01 * w[2], rel=1e-12)
+    assert t["icov"][0] == pytest.approx([icov[0, 0], icov[0, 1], icov[1, 1]], rel=1e-9)
+
+
 def test_voxel_inflation_and_rejection(oracle):
     # nearly collinear points: lambda_min inflated to 0.01 lambda_max
     x = np.linspace(0.05, 0.95, 10)
     pts = np.stack([x, 0.5 + 1e-4 * np.sin(37 * x)], 1).astype(np.float32)
-    t = oracle.Map(pts, oracle.default_params(resolution=1.0)).export()
+    t = oracle.Map(pts, oracle.default_params(resolution=1.0, cov_init_identity=0)).export()
     assert t["npts"][0] == 10
     ic = np.array([[t["icov"][0][0], t["icov"][0][1]], [t["icov"][0][1], t["icov"][0][2]]])
     w = np.linalg.eigvalsh(np.linalg.inv(ic))
     assert w[0] / w[1] == pytest.approx(0.01, rel=1e-6)
     # all points identical: zero covariance -> rejected voxel kept searchable with icov = 0
     pts = np.tile(np.array([[0.5, 0.5]], np.float32), (8, 1))
-    t = oracle.Map(pts, oracle.default_params(resolution=1.0)).export()
+    t = oracle.Map(pts, oracle.default_params(resolution=1.0, cov_init_identity=0)).export()
     assert t["npts"][0] == -8 and np.all(t["icov"][0] == 0)
+    # with the PCL 1.10 identity start the same voxel has covariance (n-1)/n^2 I: accepted
+    t = oracle.Map(pts, oracle.default_params(resolution=1.0)).export()
+    assert t["npts"][0] == 8 and t["icov"][0] == pytest.approx([64 / 7, 0.0, 64 / 7], rel=1e-12)
 
 
 def test_rejected_voxel_scores_minus_d1_only(oracle):
     pts = np.tile(np.array([[0.5, 0.5]], np.float32), (8, 1))
-    prm = oracle.default_params(resolution=1.0)
+    prm = oracle.default_params(resolution=1.0, cov_init_identity=0)
     M = oracle.Map(pts, prm)
     d1, _ = oracle.gauss(prm)
     s, g, H, pairs = M.eval_at(np.array([[0.6, 0.4]], np.float32), [0.0, 0.0, 0.0])
@@ -158,9 +212,9 @@ def test_approx_voxel_filter_flush_on_collision(oracle):
 def test_switches_change_covariance(oracle):
     rng = np.random.default_rng(1)
     pts = (rng.uniform(0.05, 0.95, size=(12, 2))).astype(np.float32)
-    base = oracle.Map(pts, oracle.default_params(resolution=1.0)).export()["icov"][0]
-    unb = oracle.Map(pts, oracle.default_params(resolution=1.0, cov_unbiased=1)).export()["icov"][0]
-    idn = oracle.Map(pts, oracle.default_params(resolution=1.0, cov_init_identity=1)).export()["icov"][0]
+    base = oracle.Map(pts, oracle.default_params(resolution=1.0, cov_unbiased=0, cov_init_identity=0)).export()["icov"][0]
+    unb = oracle.Map(pts, oracle.default_params(resolution=1.0, cov_unbiased=1, cov_init_identity=0)).export()["icov"][0]
+    idn = oracle.Map(pts, oracle.default_params(resolution=1.0, cov_unbiased=0, cov_init_identity=1)).export()["icov"][0]
     assert unb == pytest.approx(base * (11 / 12) ** 2, rel=1e-9)
     assert not np.allclose(idn, base)
     c = NP.Cells(pts, 1.0, init_identity=True)
