@@ -1,27 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- scan-matches/sec of the NDT hot path on MI355X (BASELINE.json metric).
 
-Workload (config.workload): BASELINE.json configs[2] per GPU -- a batch of 256 scans (10k points
-each) against a shared 1M-point NDT map at 0.5 m voxels; with --gpus N every rank holds its own
-256-scan shard of configs[3]'s batch (weak scaling, no data-path collective; results are gathered
-to rank 0 over RCCL).  configs[1] (one scan) is the same kernel at B = 1 and is reported as
-`single_scan_ms`.
+Workload (config.workload), default `--config C3`: BASELINE.json configs[2] per GPU -- a batch of 256 scans (10k
+points each) against a shared 1M-point NDT map at 0.5 m voxels.  With --gpus N this is configs[3]'s sharding: rank 0
+holds the N x 256-scan batch and fans the shards out over RCCL (grouped isend / irecv, device to device), every rank
+matches its shard, the result records are gathered to rank 0 (weak scaling; no collective on the data path).
+`--config C5`: BASELINE.json configs[4] per GPU -- multi-hypothesis relocalisation, 512 seed poses x one 10k-point
+scan against the 5M-point map (x 8 GPUs = the 4096 seeds of configs[4]); the scan is broadcast, the seeds are
+sharded, the best hypothesis is an arg-max over all ranks.  The default run reports C5 as a side figure
+(`multi_hypothesis`), configs[1] (one scan) as `single_scan_ms`.
 
-One step = the whole hot path over one batch with inputs resident in HBM: voxel
-normal-distributions build of the map (once per batch; the reference rebuilds it on every
-estimatePose call, src/PoseEstimator.cpp:19) + all 256 full optimisations to convergence +
-fitness scores + final Hessians, then the gather of the 256 result records.
+One step = the whole hot path over one batch with inputs resident in HBM: voxel normal-distributions build of the
+map (the reference rebuilds it on every estimatePose call, src/PoseEstimator.cpp:19) + all full optimisations to
+convergence + fitness scores + final Hessians, then the gather of the result records.
 
-Steps are pipelined the way a caller with a stream of batches would run them: two map buffers, the
-rebuild for step i + 1 is queued on a second stream and runs while the matches of step i finish
-(helper workgroups that can get no more work leave their CUs), the match launches stay in order on
-one stream and each waits for its own map's build.  `map_build_ms` is the build alone (un-overlapped),
-`map_build_in_step_ms` what the build's stream shows inside the pipelined loop.
+Steps are pipelined the way a caller with a stream of batches would run them: two map buffers, the rebuild for step
+i + 1 is queued on a second stream and runs while the matches of step i finish; with `--inflight 2` consecutive match
+launches alternate between two contexts / streams, so the owners of step i + 1 start on the CUs the helpers of step i
+have left.  `roofline.kernel_ms` is always the duration of ONE launch (HIP events on that launch's stream).
 """
 import argparse
 import json
 import math
 import os
+import platform
 import sys
 import time
 
@@ -32,6 +34,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # half the 157.3 TF fp32 vector rate (MI355X_MICROARCH.md chip table)
+SEED_SHARDS = 8           # configs[4]: 4096 seeds = 8 shards of 512; rank r takes seeds[r::8]
 
 
 def algorithmic_bytes(res, n_pts):
@@ -42,17 +46,45 @@ def algorithmic_bytes(res, n_pts):
     return float(np.sum(ev * n_pts * (8.0 + 20.0 * kb) + n_pts * 16.0))
 
 
+def _latest(pattern):
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
 def measured_traffic():
     """HBM bytes per launch of the match kernel from the PMC passes committed under profiles/
     (FETCH_SIZE + WRITE_SIZE, collected separately with rocprofv3 -- they cannot be read live here);
     None when no summary is present."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-    if not files:
+    f = _latest("r*_traffic.json")
+    if not f:
         return None, None
-    with open(files[-1]) as f:
-        t = json.load(f)
-    return float(t["bytes_per_launch"]), os.path.relpath(files[-1], ROOT)
+    with open(f) as fh:
+        t = json.load(fh)
+    return float(t["bytes_per_launch"]), os.path.relpath(f, ROOT)
+
+
+def measured_valu():
+    """SQ counter summary of the match kernel (profiles/r*_valu.json, made by tools/save_profiles.py from
+    rocprofv3 --pmc passes): instructions per point-evaluation, VALU utilisation; None when absent."""
+    f = _latest("r*_valu.json")
+    if not f:
+        return None
+    with open(f) as fh:
+        v = json.load(fh)
+    v["source"] = os.path.relpath(f, ROOT)
+    return v
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
 
 
 def main():
@@ -60,11 +92,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="scans per GPU")
+    ap.add_argument("--config", choices=["C3", "C5"], default="C3",
+                    help="C3: 256 scans x 10k vs 1M map per GPU (configs[2]/[3]); C5: 512 seeds x one scan vs 5M map per GPU (configs[4])")
+    ap.add_argument("--batch", type=int, default=None, help="matches per GPU and step (default 256 for C3, 512 for C5)")
+    ap.add_argument("--inflight", type=int, default=1, choices=[1, 2], help="match launches in flight (2: alternate two contexts)")
+    ap.add_argument("--workgroups", type=int, default=0, help="workgroups per match launch (0 = one per CU); fewer leave CUs to the map build's stream")
+    ap.add_argument("--max-helpers", type=int, default=-1, help="helper workgroups per unfinished scan (default: the library's 15); fewer free CUs earlier for the next launch")
+    ap.add_argument("--no-scatter", action="store_true", help="N > 1: every rank generates its own shard instead of receiving it from rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-single-scan", action="store_true", help="skip the configs[1] latency launches (B = 1)")
-    ap.add_argument("--cpu-sample", type=int, default=256, help="scans timed on the host cores")
-    ap.add_argument("--cpu-reps", type=int, default=4, help="times the CPU sample is run (about 10 s of CPU work in all)")
+    ap.add_argument("--no-single-scan", action="store_true", help="skip the side figures (configs[1] latency, C5 leg, rows f1-f3)")
+    ap.add_argument("--cpu-sample", type=int, default=256, help="matches timed on the host cores")
+    ap.add_argument("--cpu-reps", type=int, default=5, help="times the CPU sample is run (median reported)")
     args = ap.parse_args()
 
     import torch
@@ -90,37 +128,96 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    # point-to-point / collective payloads: device tensors over RCCL, host tensors in the gloo rehearsal
+    comm_dev = torch.device("cpu") if rehearsal else dev
 
-    cfg = synth.CONFIGS["C3"]
-    B, n_scan = args.batch, cfg["n_scan"]
-    # synthetic inputs (no reference data exists): same map on every rank, own scan shard
-    map_xy = synth.make_map(cfg["n_map"], cfg["half"])
-    sf = synth.ScanFactory(map_xy, cfg["half"], n_scan)
-    scans, off, truths, inits = sf.batch(rank * B, B)
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    ctx = capi.Context(local_rank)
-    # a dedicated (non-null) torch stream: map build, matches, events and the gather are all
-    # ordered on it (the C ABI reads a NULL stream argument as "the context's own stream")
-    stream = torch.cuda.Stream(device=dev)
+    c5 = args.config == "C5"
+    cfg = synth.CONFIGS["C5" if c5 else "C3"]
+    B = args.batch or (512 if c5 else 256)
+    n_scan = cfg["n_scan"]
+    comm = {}
+
+    # ---------------------------------------------------------------- inputs (synthetic: the reference ships no data)
+    map_xy = synth.make_map(cfg["n_map"], cfg["half"])          # the same map on every rank (built redundantly)
+    truths = None
+    if c5:
+        # one scan, broadcast from rank 0; seeds sharded: rank r takes every 8th seed of the 4096-seed lattice
+        assert world <= SEED_SHARDS and B <= cfg["seeds"] // SEED_SHARDS
+        if rank == 0 or world == 1:
+            sf = synth.ScanFactory(map_xy, cfg["half"], n_scan)
+            scan, truth, _ = sf.make(0)
+            pay = torch.from_numpy(np.concatenate([scan.ravel().astype(np.float64), truth])).to(comm_dev)
+        else:
+            pay = torch.empty(2 * n_scan + 3, dtype=torch.float64, device=comm_dev)
+        if world > 1:
+            fence()
+            t0 = time.perf_counter()
+            dist.broadcast(pay, src=0)
+            fence()
+            comm["broadcast_scan_ms"] = (time.perf_counter() - t0) * 1e3
+        pay = pay.cpu().numpy()
+        scan = pay[:2 * n_scan].astype(np.float32).reshape(-1, 2)
+        truth = pay[2 * n_scan:]
+        seeds = synth.hypothesis_seeds(truth, cfg["seeds"])
+        inits = np.ascontiguousarray(seeds[rank::SEED_SHARDS][:B])
+        d_scans = torch.from_numpy(scan).to(dev)
+        d_off = torch.tensor([0, n_scan], dtype=torch.int64, device=dev)
+        d_init = torch.from_numpy(inits).to(dev)
+        total_points = n_scan
+        scans_host, off_host = scan, np.array([0, n_scan], np.uint64)
+    elif world > 1 and not args.no_scatter:
+        # configs[3]: rank 0 holds the whole batch (N x B scans) and fans the shards out, device to device
+        if rank == 0:
+            sf = synth.ScanFactory(map_xy, cfg["half"], n_scan)
+            scans_all, off_all, truths_all, inits_all = sf.batch(0, world * B)
+        else:
+            scans_all = off_all = inits_all = None
+        fence()
+        t0 = time.perf_counter()
+        d_scans, d_off, d_init = shard.scatter_batch(scans_all, off_all, inits_all, src=0, device=comm_dev)
+        fence()
+        comm["scatter_ms"] = (time.perf_counter() - t0) * 1e3
+        comm["scatter_bytes"] = int(world * B * n_scan * 8)
+        d_scans, d_off, d_init = d_scans.to(dev), d_off.to(dev), d_init.to(dev)
+        total_points = int(d_scans.shape[0])
+        if rank == 0:
+            scans_host, off_host, inits = shard.shard_batch(scans_all, off_all, inits_all, world, 0)
+            truths = truths_all[:B]
+    else:
+        sf = synth.ScanFactory(map_xy, cfg["half"], n_scan)
+        scans_host, off_host, truths, inits = sf.batch(rank * B, B)
+        d_scans = torch.from_numpy(scans_host).to(dev)
+        d_off = torch.from_numpy(off_host.astype(np.int64)).to(dev)
+        d_init = torch.from_numpy(inits).to(dev)
+        total_points = len(scans_host)
+
+    # ---------------------------------------------------------------- contexts, streams, buffers
+    # match launches: `inflight` contexts, each with its own stream and scratch; map builds: one more context
+    streams = [torch.cuda.Stream(device=dev) for _ in range(args.inflight)]
+    mctx = [capi.Context(local_rank) for _ in range(args.inflight)]
+    for c, s in zip(mctx, streams):
+        assert s.cuda_stream != 0
+        c.set_stream(s.cuda_stream)
+        if args.workgroups:
+            c.set_option(capi.OPT_WORKGROUPS, args.workgroups)
+        if args.max_helpers >= 0:
+            c.set_option(capi.OPT_MAX_HELPERS, args.max_helpers)
+    stream, ctx = streams[0], mctx[0]
     torch.cuda.set_stream(stream)
-    assert stream.cuda_stream != 0
-    ctx.set_stream(stream.cuda_stream)
-    prm = capi.default_params(resolution=cfg["resolution"])     # otherwise ndt_mapping.launch:32-36
+    prm = capi.default_params(resolution=cfg["resolution"])     # PCL 1.10 preset; otherwise ndt_mapping.launch:32-36
     d_map = torch.from_numpy(map_xy).to(dev)
-    d_scans = torch.from_numpy(scans).to(dev)
-    d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
-    d_init = torch.from_numpy(inits).to(dev)
     d_res2 = [torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev) for _ in range(2)]
-    d_res = d_res2[0]
-    # the gather of step i runs on a side stream while step i + 1 is already computing
-    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    side = torch.cuda.Stream(device=dev) if world > 1 else None      # gather of step i while step i + 1 computes
     ev_done = [torch.cuda.Event() for _ in range(2)]
     gathered = [None, None]
     torch.cuda.synchronize()
-    # Two voxel grids, built by a second context on its own stream: the rebuild of step i + 1 runs while
-    # the matches of step i finish (their last workgroups leave CUs free), the matches themselves stay in
-    # order on `stream`.  Every step still rebuilds its map and then matches against it.
-    bstream = torch.cuda.Stream(device=dev)
+    bstream = torch.cuda.Stream(device=dev, priority=-1)     # map builds: small kernels, first in line for freed CUs
     bctx = capi.Context(local_rank)
     bctx.set_stream(bstream.cuda_stream)
     gmaps = [capi.Map(bctx, params=prm, dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8) for _ in range(2)]
@@ -132,11 +229,16 @@ def main():
         solo_build_ms.append(bctx.last_timing()[0])
     torch.cuda.synchronize()
 
-    ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup))]
-    ev_m = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup))]
+    nst = args.steps + args.warmup
+    ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(2 * nst)]
+    ev_m = [torch.cuda.Event(enable_timing=True) for _ in range(2 * nst)]
+    best_log = []
+    tp_off = capi.RESULT_DTYPE.fields["trans_prob"][1]
+    seed_index = (rank + SEED_SHARDS * torch.arange(B, dtype=torch.int64)).to(comm_dev) if c5 else None
 
     def step(i):
         gm = gmaps[i & 1]
+        st, cx = streams[i % args.inflight], mctx[i % args.inflight]
         # a2: rebuild the voxel grid of this step in place, as soon as the matches of step i - 2 (the last
         # readers of this grid) are done
         if i >= 2:
@@ -144,100 +246,180 @@ def main():
         ev_m[2 * i].record(bstream)
         gm.rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
         ev_m[2 * i + 1].record(bstream)
-        # a3-a9 for the whole batch: one launch on `stream`, after this step's build (the library waits
-        # for it too; waiting here keeps that wait out of the kernel's event interval)
-        stream.wait_event(ev_m[2 * i + 1])
+        # a3-a9 for the whole batch: one launch, after this step's build (the library waits for it too;
+        # waiting here keeps that wait out of the kernel's event interval)
+        st.wait_event(ev_m[2 * i + 1])
         out = d_res2[i & 1]
         if world > 1:
-            stream.wait_event(ev_done[i & 1])          # the gather that last read this result buffer has finished
-        ev_a[2 * i].record(stream)
-        gm.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, len(scans), d_init.data_ptr(),
-                           out.data_ptr(), stream=stream.cuda_stream)
-        ev_a[2 * i + 1].record(stream)                 # (also what the rebuild of step i + 2 waits for)
-        if world > 1:    # gather of poses (the only collective on this path)
-            side.wait_stream(stream)
+            st.wait_event(ev_done[i & 1])              # the gather that last read this result buffer has finished
+        ev_a[2 * i].record(st)
+        gm.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, total_points, d_init.data_ptr(),
+                           out.data_ptr(), shared_scan=c5, stream=st.cuda_stream, ctx=cx)
+        ev_a[2 * i + 1].record(st)                     # (also what the rebuild of step i + 2 waits for)
+        if world > 1 and not c5:    # gather of poses (the only collective on this path)
+            side.wait_stream(st)
             with torch.cuda.stream(side):
-                gathered[i & 1] = shard.gather_results(out, dst=0)
+                gathered[i & 1] = shard.gather_results(out if not rehearsal else out.cpu(), dst=0)
                 ev_done[i & 1].record(side)
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        if world > 1 and c5:        # configs[4]: arg-max of the hypothesis scores over all ranks (a few bytes)
+            side.wait_stream(st)
+            with torch.cuda.stream(side):
+                tp = out.view(B, capi.RESULT_BYTES)[:, tp_off:tp_off + 8].contiguous().view(torch.float64).reshape(B)
+                best_log.append(shard.best_hypothesis_t(tp.to(comm_dev), seed_index))    # stays on the device
+                ev_done[i & 1].record(side)
 
     for i in range(args.warmup):
         step(i)
     fence()
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
+    for i in range(args.warmup, nst):
         step(i)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = [ev_a[2 * i].elapsed_time(ev_a[2 * i + 1]) for i in range(args.warmup, args.warmup + args.steps)]
-    map_ms = [ev_m[2 * i].elapsed_time(ev_m[2 * i + 1]) for i in range(args.warmup, args.warmup + args.steps)]
-    last = (args.warmup + args.steps - 1) & 1
+    kern_ms = [ev_a[2 * i].elapsed_time(ev_a[2 * i + 1]) for i in range(args.warmup, nst)]
+    map_ms = [ev_m[2 * i].elapsed_time(ev_m[2 * i + 1]) for i in range(args.warmup, nst)]
+    last = (nst - 1) & 1
     res = np.frombuffer(d_res2[last].cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
     assert np.all(res["status"] == 0)
+    avg_kern_ms = float(np.mean(kern_ms))
+    per_rank = None
+    if world > 1:      # per-rank kernel and step figures, so that imbalance across ranks is visible in the SCALE record
+        mine = torch.tensor([avg_kern_ms, float(np.max(kern_ms)), float(res["evals"].sum())], dtype=torch.float64, device=comm_dev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = {"kernel_ms": [float(t[0]) for t in allr], "kernel_ms_max": [float(t[1]) for t in allr],
+                    "evals": [float(t[2]) for t in allr]}
 
     out = None
     if rank == 0:
-        avg_kern_ms = float(np.mean(kern_ms))
         traffic, traffic_src = measured_traffic()
         alg_bytes = algorithmic_bytes(res, n_scan)
         achieved = alg_bytes / (avg_kern_ms * 1e-3) / 1e9
-        err = res["pose"] - truths
-        err[:, 2] = (err[:, 2] + math.pi) % (2 * math.pi) - math.pi
+        accepted = (res["converged"] == 1) & (res["fitness"] <= 0.5)      # src/ScanMatcher.cpp:50 with score_thre 0.5
+        what = ("BASELINE configs[4] share of one GPU: %d seed poses x one %d-pt scan vs %d-pt map, 0.5 m voxels (x%d ranks of the "
+                "8 x 512 = 4096-seed lattice)" % (B, n_scan, cfg["n_map"], world)) if c5 else (
+                "BASELINE configs[2]: batch of %d scans x %d pts vs shared %d-pt map, 0.5 m voxels, per GPU (configs[3] sharding "
+                "at N>1)" % (B, n_scan, cfg["n_map"]))
         out = {
-            "metric": "scan-matches/sec (10k-pt scan vs 1M-pt NDT map)",
+            "metric": "scan-matches/sec (10k-pt scan vs 1M-pt NDT map)" if not c5 else "scan-matches/sec (seed poses of one 10k-pt scan vs 5M-pt NDT map)",
             "value": world * B * args.steps / elapsed,
             "unit": "matches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: batch of %d scans x %d pts vs shared %d-pt map, 0.5 m "
-                                   "voxels, per GPU (configs[3] sharding at N>1); map rebuilt every step (the rebuild of step i+1 overlaps the end of step i's matches)"
-                                   % (B, n_scan, cfg["n_map"]),
-                       "scans_per_gpu": B, "scan_points": n_scan, "map_points": cfg["n_map"],
-                       "resolution": cfg["resolution"], "parallelism": "scan-shards x%d, gather of results" % world},
+            "config": {"workload": what + "; map rebuilt every step (the rebuild of step i+1 overlaps the end of step i's matches); "
+                                   "%d match launch(es) in flight; parameter preset PCL 1.10" % args.inflight,
+                       "matches_per_gpu": B, "scans_per_gpu": B if not c5 else 1, "scan_points": n_scan, "map_points": cfg["n_map"],
+                       "resolution": cfg["resolution"], "inflight": args.inflight, "workgroups": args.workgroups, "max_helpers": args.max_helpers,
+                       "parallelism": ("seed-shards x%d, scan broadcast, arg-max of scores" % world) if c5 else
+                                      ("scan-shards x%d, %s, gather of results" % (world, "every rank generates its shard" if (args.no_scatter or world == 1) else "scatter from rank 0"))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "note": "achieved = SURVEY 8d algorithmic bytes / kernel time.  The kernel is VALU-issue bound, "
-                                 "not HBM bound: each voxel record is staged once per match in LDS, so the measured HBM "
-                                 "traffic is below the algorithmic bytes (DESIGN.md 4.7)",
+                         "note": "achieved = SURVEY 8d algorithmic bytes of one launch / duration of one launch.  The kernel is "
+                                 "VALU-issue bound, not HBM bound: each voxel record is staged once per match in LDS, so the "
+                                 "measured HBM traffic is below the algorithmic bytes (DESIGN.md 4.7)",
                          "kernel": "ndt_align_kernel", "kernel_ms": avg_kern_ms,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "mean_evals": float(res["evals"].mean()), "max_evals": int(res["evals"].max()),
                          "mean_kbar": float(res["kbar"].mean())},
             "map_build_ms": float(np.median(solo_build_ms)), "map_build_in_step_ms": float(np.mean(map_ms)),
             "converged": int(res["converged"].sum()),
-            "median_abs_err_m": float(np.median(np.hypot(err[:, 0], err[:, 1]))),
+            "accepted": int(accepted.sum()), "accepted_frac": float(accepted.mean()),
         }
+        # fp64 arithmetic rate next to the byte rate (SURVEY 8d asks for it so that the HBM figure is not misread):
+        # per (point, voxel) pair ~ 100 flops, per point-evaluation ~ 60 (transform, voxel index, 9 radius tests)
+        pe = float(np.sum(res["evals"].astype(np.float64) * n_scan))
+        flops = pe * 60.0 + float(np.sum(res["evals"] * res["kbar"])) * n_scan * 100.0
+        valu = measured_valu() or {}
+        valu.update({"point_evals_per_launch": pe, "flops_per_launch_estimate": flops,
+                     "fp64_frac_of_peak": flops / (avg_kern_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                     "point_evals_per_us": pe / (avg_kern_ms * 1e3)})
+        out["roofline"]["valu"] = valu
+        if truths is not None:
+            err = res["pose"] - truths
+            err[:, 2] = (err[:, 2] + math.pi) % (2 * math.pi) - math.pi
+            out["median_abs_err_m"] = float(np.median(np.hypot(err[:, 0], err[:, 1])))
+        if c5:
+            best = int(np.argmax(res["trans_prob"]))
+            out["best_hypothesis"] = {"local_index": best, "trans_prob": float(res["trans_prob"][best]),
+                                      "err_m": float(np.hypot(*(res["pose"][best][:2] - truth[:2])))}
+            if best_log:
+                out["best_hypothesis"]["global"] = {"trans_prob": float(best_log[-1][0].item()), "seed": int(best_log[-1][1].item())}
+        if comm:
+            out["comm"] = comm
+        if per_rank:
+            out["per_rank"] = per_rank
 
-    # configs[1]: one scan (latency of a single match, same kernel at B = 1)
-    if rank == 0 and world == 1 and not args.no_single_scan:
+    side_figures = rank == 0 and world == 1 and not args.no_single_scan
+    # configs[1]: one scan (latency of a single match, same kernel at B = 1), with every idle CU helping and alone
+    if side_figures and not c5:
         one = torch.zeros(capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ts = []
-        for _ in range(5):
+
+        def one_scan(cx):
+            ts = []
+            for _ in range(5):
+                e0.record(stream)
+                gmap.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), 1, int(off_host[1]), d_init.data_ptr(),
+                                     one.data_ptr(), stream=stream.cuda_stream, ctx=cx)
+                e1.record(stream)
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            return float(np.median(ts))
+        out["single_scan_ms"] = one_scan(ctx)
+        r1 = np.frombuffer(one.cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)[0]
+        solo_ctx = capi.Context(local_rank)
+        solo_ctx.set_stream(stream.cuda_stream)
+        solo_ctx.set_option(capi.OPT_MAX_HELPERS, 0)
+        solo_ms = one_scan(solo_ctx)
+        # per-evaluation latency: one derivative pass over the 10k points of one scan (setup and the fitness pass
+        # included in the numerator, so an upper bound), by one workgroup alone and with the idle CUs helping
+        out["per_eval_us"] = {"one_workgroup": 1e3 * solo_ms / int(r1["evals"]), "all_cus_helping": 1e3 * out["single_scan_ms"] / int(r1["evals"]),
+                              "evals": int(r1["evals"]), "single_scan_one_workgroup_ms": solo_ms}
+        solo_ctx.close()
+
+    # configs[4] as a side figure of the default run: 512 seeds x one scan vs a 5M-point map (map rebuild + matches)
+    if side_figures and not c5:
+        cfg5 = synth.CONFIGS["C5"]
+        m5 = synth.make_map(cfg5["n_map"], cfg5["half"])
+        sf5 = synth.ScanFactory(m5, cfg5["half"], cfg5["n_scan"])
+        sc5, truth5, _ = sf5.make(0)
+        seeds5 = np.ascontiguousarray(synth.hypothesis_seeds(truth5, cfg5["seeds"])[0::SEED_SHARDS])
+        d_m5 = torch.from_numpy(m5).to(dev); d_s5 = torch.from_numpy(sc5).to(dev)
+        d_o5 = torch.tensor([0, len(sc5)], dtype=torch.int64, device=dev); d_i5 = torch.from_numpy(seeds5).to(dev)
+        d_r5 = torch.zeros(len(seeds5) * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+        g5 = capi.Map(ctx, params=capi.default_params(resolution=cfg5["resolution"]), dev_ptr=d_m5.data_ptr(), n=len(m5), stride=8)
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        tb, tm = [], []
+        for _ in range(4):
             e0.record(stream)
-            gmap.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), 1, int(off[1]), d_init.data_ptr(),
-                                 one.data_ptr(), stream=stream.cuda_stream)
+            g5.rebuild(dev_ptr=d_m5.data_ptr(), n=len(m5), stride=8)
             e1.record(stream)
+            g5.align_batch_dev(d_s5.data_ptr(), d_o5.data_ptr(), len(seeds5), len(sc5), d_i5.data_ptr(), d_r5.data_ptr(),
+                               shared_scan=True, stream=stream.cuda_stream)
+            e2.record(stream)
             torch.cuda.synchronize()
-            ts.append(e0.elapsed_time(e1))
-        out["single_scan_ms"] = float(np.median(ts))
+            tb.append(e0.elapsed_time(e1)); tm.append(e1.elapsed_time(e2))
+        r5 = np.frombuffer(d_r5.cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
+        b5 = int(np.argmax(r5["trans_prob"]))
+        out["multi_hypothesis"] = {"workload": "configs[4] share of one GPU: %d seeds x one %d-pt scan vs %d-pt map" % (len(seeds5), len(sc5), len(m5)),
+                                   "map_build_ms": float(np.median(tb[1:])), "match_ms": float(np.median(tm[1:])),
+                                   "seeds_per_s": len(seeds5) / (float(np.median(tm[1:])) * 1e-3),
+                                   "mean_evals": float(r5["evals"].mean()), "best_seed_err_m": float(np.hypot(*(r5["pose"][b5][:2] - truth5[:2])))}
+        g5.close()
+        del d_m5, d_r5
 
     # Row f1 (source pre-filter, pcl::ApproximateVoxelGrid): raw scans 3x oversampled -> filtered scans,
     # all on the device; reported beside the headline metric, not part of it (the 10k-pt scans of the
     # metric are post-filter clouds by definition).
-    if rank == 0 and world == 1 and not args.no_single_scan:
+    if side_figures and not c5:
+        scans, off = scans_host, off_host
         rng = np.random.default_rng(11)
         raw = np.repeat(scans, 3, axis=0) + rng.normal(0, 0.004, (3 * len(scans), 2)).astype(np.float32)
         raw_off = (off.astype(np.int64) * 3)
@@ -267,6 +449,7 @@ def main():
         d_fu = torch.zeros_like(d_prevo); d_cv = torch.zeros(B, 9, dtype=torch.float64, device=dev)
         d_ok = torch.zeros(B, dtype=torch.int32, device=dev)
         fprm = capi.default_fuse_params(score_thre=0.5)
+        fmap = capi.Map(ctx, params=prm, dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
         ts = []
         for _ in range(5):
             e0.record(stream)
@@ -274,8 +457,8 @@ def main():
                                   d_pred.data_ptr(), d_in2.data_ptr(), stream=stream.cuda_stream)
             ctx.prefilter_batch_dev(d_raw.data_ptr(), 8, d_roff.data_ptr(), B, len(raw), 0.05, d_f.data_ptr(),
                                     d_foff.data_ptr(), stream=stream.cuda_stream)
-            gmap.rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
-            gmap.align_batch_dev(d_f.data_ptr(), d_foff.data_ptr(), B, len(raw), d_in2.data_ptr(), d_res2[0].data_ptr(),
+            fmap.rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
+            fmap.align_batch_dev(d_f.data_ptr(), d_foff.data_ptr(), B, len(raw), d_in2.data_ptr(), d_res2[0].data_ptr(),
                                  stream=stream.cuda_stream)
             ctx.fuse_batch_dev(d_res2[0].data_ptr(), d_pred.data_ptr(), d_mo.data_ptr(), d_last.data_ptr(), d_lc.data_ptr(), B,
                                fprm, d_fu.data_ptr(), d_cv.data_ptr(), d_ok.data_ptr(), stream=stream.cuda_stream)
@@ -285,12 +468,13 @@ def main():
         out["front_end_step"] = {"stages": "predict + pre-filter + map rebuild + match + fuse, all on the device",
                                  "scans": B, "raw_points_per_scan": int(len(raw) // B), "ms": float(np.median(ts)),
                                  "scans_per_s": B / (float(np.median(ts)) * 1e-3), "accepted": int(d_ok.sum().item())}
+        fmap.close()
 
     # Row f3 (local-map assembly, Submap::makeMap with moving-object removal): a submap of 12 registered scans
     # of the metric's size (walls seen again by every scan + an object that moves, synth.submap_scans) assembled
     # on the device; the oracle's literal octree does the same on one host core (checker and CPU figure).
     # Reported beside the headline metric, not part of it.
-    if rank == 0 and world == 1 and not args.no_single_scan:
+    if side_figures and not c5:
         ns = 12
         reg = synth.submap_scans(ns, cfg["n_scan"])
         reg_off = np.zeros(ns + 1, np.uint64)
@@ -319,28 +503,39 @@ def main():
         out["local_map"] = lm
 
     # CPU baseline: the oracle (a port -- PCL itself is absent) on this box's host cores,
-    # rank 0 at N = 1 only, on a bounded sample of the same batch.
+    # rank 0 at N = 1 only, on a bounded sample of the same batch (median of --cpu-reps repetitions).
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ndt_oracle as O
         ns = min(args.cpu_sample, B)
         t = time.perf_counter()
         om = O.Map(map_xy, O.default_params(resolution=cfg["resolution"]))
         t_build = time.perf_counter() - t
-        sub_off = off[:ns + 1]
-        t = time.perf_counter()
-        for _ in range(max(1, args.cpu_reps)):
-            ref = om.align_batch(scans[:int(sub_off[-1])], sub_off, inits[:ns], nthreads=1)
-        t_align = (time.perf_counter() - t) / max(1, args.cpu_reps)
+        reps = max(1, args.cpu_reps)
+        if c5:
+            run = lambda nt: om.align_batch(scans_host, off_host, inits[:ns], nthreads=nt, shared_scan=True)
+        else:
+            sub_off = off_host[:ns + 1]
+            run = lambda nt: om.align_batch(scans_host[:int(sub_off[-1])], sub_off, inits[:ns], nthreads=nt)
+        run(1)                                   # one warm-up, excluded
+        t1 = []
+        for _ in range(reps):
+            t = time.perf_counter()
+            ref = run(1)
+            t1.append(time.perf_counter() - t)
         ncpu = min(16, os.cpu_count() or 1)     # the box's CPU share for one GPU
-        t = time.perf_counter()
-        om.align_batch(scans[:int(sub_off[-1])], sub_off, inits[:ns], nthreads=ncpu)
-        t_all = time.perf_counter() - t
+        tn = []
+        for _ in range(min(reps, 3)):
+            t = time.perf_counter()
+            run(ncpu)
+            tn.append(time.perf_counter() - t)
+        t_align, t_all = float(np.median(t1)), float(np.median(tn))
         d = res["pose"][:ns] - ref["pose"]
         d[:, 2] = (d[:, 2] + math.pi) % (2 * math.pi) - math.pi
         out["cpu_baseline"] = {
             "value": ns / t_align, "unit": "matches/s", "cores": 1, "kind": "port",
-            "sample": "first %d of the %d scans x %d repetitions, 1 thread, map built once (amortised); oracle/ndt_oracle.c"
-                      % (ns, B, max(1, args.cpu_reps)),
+            "sample": "first %d of the %d matches, median of %d repetitions (one warm-up excluded), 1 thread, map built once "
+                      "(amortised); oracle/ndt_oracle.c, -O2, grid-hash neighbour lookup (faster than PCL's kd-tree)" % (ns, B, reps),
+            "cpu_model": cpu_model(), "nproc": os.cpu_count(),
             "map_build_s": t_build,
             "reference_faithful_matches_per_s": 1.0 / (t_build + t_align / ns),
             "all_cores": {"value": ns / t_all, "cores": ncpu},

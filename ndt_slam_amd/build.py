@@ -25,17 +25,22 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not needs_build():
+def build(force=False, verbose=False, extra=(), out=None):
+    """out: another output path (diagnostic / experimental variants, loaded through NDT_LIB_PATH)."""
+    if out is None and not force and not needs_build():
         return OUT
-    cmd = [HIPCC] + FLAGS + list(extra) + ["-o", OUT, SRC]
+    cmd = [HIPCC] + FLAGS + list(extra) + ["-o", out or OUT, SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return OUT
+    return out or OUT
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, verbose=True,
-          extra=["-Rpass-analysis=kernel-resource-usage"] if "--usage" in sys.argv else [])
-    print(OUT)
+    # python -m ndt_slam_amd.build [--force] [--usage] [--out PATH] [-DNAME[=V] ...]
+    argv = sys.argv[1:]
+    out = argv[argv.index("--out") + 1] if "--out" in argv else None
+    extra = [a for a in argv if a.startswith("-D")]
+    if "--usage" in argv:
+        extra.append("-Rpass-analysis=kernel-resource-usage")
+    print(build(force="--force" in argv, verbose=True, extra=extra, out=out))

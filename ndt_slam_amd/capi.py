@@ -322,11 +322,12 @@ class Map:
         return res
 
     def align_batch_dev(self, scans_ptr, offsets_ptr, B, total_points, inits_ptr, out_ptr, shared_scan=False,
-                        stream=None):
-        """All pointers are device addresses (e.g. torch.Tensor.data_ptr()); asynchronous."""
-        self.ctx.check(lib().ndt_align_batch_dev(self.ctx.h, self.h, scans_ptr, offsets_ptr, B, total_points,
-                                                 int(shared_scan), inits_ptr, out_ptr, stream),
-                       "ndt_align_batch_dev")
+                        stream=None, ctx=None):
+        """All pointers are device addresses (e.g. torch.Tensor.data_ptr()); asynchronous.  `ctx`: the context
+        whose scratch the launch uses (default: the map's own) -- two contexts keep two batches in flight."""
+        cx = ctx if ctx is not None else self.ctx
+        cx.check(lib().ndt_align_batch_dev(cx.h, self.h, scans_ptr, offsets_ptr, B, total_points,
+                                           int(shared_scan), inits_ptr, out_ptr, stream), "ndt_align_batch_dev")
 
     def eval_at(self, scan, p):
         scan = _f32c(scan)

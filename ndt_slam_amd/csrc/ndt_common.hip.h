@@ -56,6 +56,31 @@ struct AlignState {
 // small device helpers
 // ------------------------------------------------------------------------------------------
 
+// Loads through a pointer that is known to address device memory.  A pointer that reached a function through LDS
+// (pass_units) has lost its address space: the compiler then emits flat_load, which counts on vmcnt AND lgkmcnt,
+// so every LDS read behind it waits for the memory load as well (the software prefetch of the point loop was
+// waited for at once).  These helpers put the address space back: global_load.
+#define NDT_GLOBAL __attribute__((address_space(1)))
+typedef float ndt_f2v __attribute__((ext_vector_type(2)));
+typedef float ndt_f4v __attribute__((ext_vector_type(4)));
+typedef double ndt_d2v __attribute__((ext_vector_type(2)));
+typedef int ndt_i4v __attribute__((ext_vector_type(4)));
+typedef int ndt_i2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2 gld_f2(const float2 *p) {
+  const ndt_f2v v = *(const NDT_GLOBAL ndt_f2v *)p;
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float4 gld_f4(const float4 *p) {
+  const ndt_f4v v = *(const NDT_GLOBAL ndt_f4v *)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ double2 gld_d2(const double *p) {
+  const ndt_d2v v = *(const NDT_GLOBAL ndt_d2v *)p;
+  return make_double2(v.x, v.y);
+}
+__device__ __forceinline__ double gld_d(const double *p) { return *(const NDT_GLOBAL double *)p; }
+__device__ __forceinline__ int gld_i(const int *p) { return *(const NDT_GLOBAL int *)p; }
+
 __device__ __forceinline__ float2 load_pt(const float *xy, size_t stride, size_t i) {
   return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(xy) + i * stride);
 }

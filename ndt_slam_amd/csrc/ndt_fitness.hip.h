@@ -12,47 +12,69 @@
 // layout allows: a bucket's points two per 16-byte load, and the offsets of up to three
 // neighbouring voxels of a row in one 16-byte load (pt_start carries 4 readable ints before its
 // first entry and 3 after its last one).
-struct __attribute__((packed, aligned(4))) I4u { int x, y, z, w; };
-struct __attribute__((packed, aligned(4))) I2u { int x, y; };
-__device__ __forceinline__ I4u ld_i4u(const int *p) { I4u v; __builtin_memcpy(&v, p, 16); return v; }
-__device__ __forceinline__ I2u ld_i2u(const int *p) { I2u v; __builtin_memcpy(&v, p, 8); return v; }
+struct I4u { int x, y, z, w; };
+struct I2u { int x, y; };
+typedef ndt_i4v ndt_i4v_u __attribute__((aligned(4)));      // 16 bytes at 4-byte alignment: one dwordx4 load
+typedef ndt_i2v ndt_i2v_u __attribute__((aligned(4)));
+__device__ __forceinline__ I4u ld_i4u(const int *p) { const ndt_i4v v = *(const NDT_GLOBAL ndt_i4v_u *)p; return I4u{v.x, v.y, v.z, v.w}; }
+__device__ __forceinline__ I2u ld_i2u(const int *p) { const ndt_i2v v = *(const NDT_GLOBAL ndt_i2v_u *)p; return I2u{v.x, v.y}; }
 
 __device__ __forceinline__ float sq_dist(float qx, float qy, float px, float py) {
   const float ex = qx - px, ey = qy - py;
   return ex * ex + ey * ey;
 }
 
-// min over the points pts[s .. se) of the float32 squared distance to (qx, qy)
+// min over the points pts[s .. se) of the float32 squared distance to (qx, qy).
+// The search is bound by the latency of its dependent loads (offsets -> bucket -> next bucket ...), so a bucket is
+// fetched kFitWide 16-byte loads (two points each) at a time, all in flight together; loads past the end of the
+// bucket re-read its last pair and are masked out.
+#ifndef NDT_FIT_WIDE
+#define NDT_FIT_WIDE 6
+#endif
+constexpr int kFitWide = NDT_FIT_WIDE;
 __device__ __forceinline__ float scan_bucket(const float2 *__restrict__ pts, int s, int se, float qx,
                                              float qy, float best) {
   if (s >= se) return best;
-  if (s & 1) { const float2 p = pts[s]; best = fminf(best, sq_dist(qx, qy, p.x, p.y)); ++s; }
+  if (s & 1) { const float2 p = gld_f2(pts + s); best = fminf(best, sq_dist(qx, qy, p.x, p.y)); ++s; }
   const float4 *__restrict__ p4 = reinterpret_cast<const float4 *>(pts + s);   // 16-byte aligned
   const int npair = (se - s) >> 1;
-  int i = 0;
-  for (; i + 2 <= npair; i += 2) {           // four points, two loads in flight
-    const float4 a = p4[i], b = p4[i + 1];
-    const float d0 = sq_dist(qx, qy, a.x, a.y), d1 = sq_dist(qx, qy, a.z, a.w);
-    const float d2 = sq_dist(qx, qy, b.x, b.y), d3 = sq_dist(qx, qy, b.z, b.w);
-    best = fminf(best, fminf(fminf(d0, d1), fminf(d2, d3)));
+  for (int i = 0; i < npair; i += kFitWide) {
+    float4 v[kFitWide];
+#pragma unroll
+    for (int u = 0; u < kFitWide; ++u) v[u] = gld_f4(p4 + min(i + u, npair - 1));
+#pragma unroll
+    for (int u = 0; u < kFitWide; ++u) {
+      const float d = fminf(sq_dist(qx, qy, v[u].x, v[u].y), sq_dist(qx, qy, v[u].z, v[u].w));
+      best = fminf(best, (i + u < npair) ? d : INFINITY);
+    }
   }
-  if (i < npair) {
-    const float4 a = p4[i];
-    best = fminf(best, fminf(sq_dist(qx, qy, a.x, a.y), sq_dist(qx, qy, a.z, a.w)));
-  }
-  if ((se - s) & 1) { const float2 p = pts[se - 1]; best = fminf(best, sq_dist(qx, qy, p.x, p.y)); }
+  if ((se - s) & 1) { const float2 p = gld_f2(pts + se - 1); best = fminf(best, sq_dist(qx, qy, p.x, p.y)); }
   return best;
 }
 
-__device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy) {
+// The search in two halves so that a caller can have the next query's offsets in flight while this query's
+// buckets are read: nearest_prep issues the one load everything else depends on.
+struct NearPrep { int cx, cy; bool inside; I4u h, dn, up; };
+__device__ __forceinline__ NearPrep nearest_prep(const MapView &M, float qx, float qy) {
+  NearPrep P;
   const int cx0 = (int)floorf(qx * M.inv_leaf) - M.min_bx, cy0 = (int)floorf(qy * M.inv_leaf) - M.min_by;
-  const int cx = cx0 < 0 ? 0 : (cx0 >= M.div_x ? M.div_x - 1 : cx0);
-  const int cy = cy0 < 0 ? 0 : (cy0 >= M.div_y ? M.div_y - 1 : cy0);
-  const bool inside = (cx == cx0) && (cy == cy0);
-  const int *__restrict__ ps = M.pt_start;
-  const size_t gh = (size_t)cy * M.div_x + cx;
+  P.cx = cx0 < 0 ? 0 : (cx0 >= M.div_x ? M.div_x - 1 : cx0);
+  P.cy = cy0 < 0 ? 0 : (cy0 >= M.div_y ? M.div_y - 1 : cy0);
+  P.inside = (P.cx == cx0) && (P.cy == cy0);
   // offsets of (cx-1, cx, cx+1) of the home row in one load: [left, home) [home, right) [right, end)
-  const I4u h = ld_i4u(ps + gh - 1);
+  const int *row = M.pt_start + ((size_t)P.cy * M.div_x + P.cx) - 1;
+  P.h = ld_i4u(row);
+  // the same for the rows below and above (clamped at the grid's edge; used only when that row exists)
+  P.dn = ld_i4u(P.cy > 0 ? row - M.div_x : row);
+  P.up = ld_i4u(P.cy + 1 < M.div_y ? row + M.div_x : row);
+  return P;
+}
+
+__device__ __forceinline__ float nearest_finish(const MapView &M, float qx, float qy, const NearPrep &P) {
+  const int cx = P.cx, cy = P.cy;
+  const bool inside = P.inside;
+  const int *__restrict__ ps = M.pt_start;
+  const I4u h = P.h;
   float best = scan_bucket(M.pts, h.y, h.z, qx, qy, INFINITY);
   // distances from the query to the four walls of its voxel, shrunk by 1e-3 leaf so that a point
   // the float32 voxel rounding put on the other side of a wall is never pruned away
@@ -63,20 +85,42 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
   if (!inside) { wl = wr = wd = wu = 0.f; }            // clamped query: no pruning
   const float wmin = fminf(fminf(wl, wr), fminf(wd, wu));
   if (!(wmin * wmin < best)) return best;              // no other voxel can hold a closer point
-  // ring 1: left / right voxel of the home row, then the rows below and above as one range each,
-  // every voxel pruned by its box distance
+  // ring 1: left / right voxel of the home row and the rows below and above as one range each, every voxel pruned
+  // by its box distance against the home voxel's best.  The (up to four) ranges are walked as ONE sequence, kRingWide
+  // points in flight: four loops one after the other cost four chains of dependent loads per wave, because some
+  // lane of a wave nearly always needs each of them.  (Pruning against `best` as it was after the home voxel scans
+  // a few more points than pruning range by range; the minimum over a larger set of map points is the same.)
   const bool has_l = cx > 0, has_r = cx + 1 < M.div_x;
-  if (has_l && wl * wl < best) best = scan_bucket(M.pts, h.x, h.y, qx, qy, best);
-  if (has_r && wr * wr < best) best = scan_bucket(M.pts, h.z, h.w, qx, qy, best);
+  int rs[4], rn[4];
+  rs[0] = h.x; rn[0] = (has_l && wl * wl < best) ? h.y - h.x : 0;
+  rs[1] = h.z; rn[1] = (has_r && wr * wr < best) ? h.w - h.z : 0;
 #pragma unroll
-  for (int dy = -1; dy <= 1; dy += 2) {
-    const int yy = cy + dy;
-    const float by = dy < 0 ? wd : wu;
-    if (yy < 0 || yy >= M.div_y || !(by * by < best)) continue;
-    const I4u o = ld_i4u(ps + (size_t)yy * M.div_x + cx - 1);
+  for (int d = 0; d < 2; ++d) {
+    const int yy = cy + (d ? 1 : -1);
+    const float by = d ? wu : wd;
+    const I4u o = d ? P.up : P.dn;
+    const bool row_ok = yy >= 0 && yy < M.div_y && (by * by < best);
     const int sa = (has_l && wl * wl + by * by < best) ? o.x : o.y;
     const int sb = (has_r && wr * wr + by * by < best) ? o.w : o.z;
-    best = scan_bucket(M.pts, sa, sb, qx, qy, best);
+    rs[2 + d] = sa; rn[2 + d] = row_ok ? sb - sa : 0;
+  }
+  {
+    constexpr int kRingWide = 8;
+    const int c1 = rn[0], c2 = c1 + rn[1], c3 = c2 + rn[2], total = c3 + rn[3];
+    // start of range j minus the number of points before it: index of sequence position t is off[j] + t
+    const int o0 = rs[0], o1 = rs[1] - c1, o2 = rs[2] - c2, o3 = rs[3] - c3;
+    for (int t0 = 0; t0 < total; t0 += kRingWide) {
+      float2 v[kRingWide];
+#pragma unroll
+      for (int u = 0; u < kRingWide; ++u) {
+        const int t = min(t0 + u, total - 1);
+        const int off = t < c1 ? o0 : (t < c2 ? o1 : (t < c3 ? o2 : o3));
+        v[u] = gld_f2(M.pts + (off + t));
+      }
+#pragma unroll
+      for (int u = 0; u < kRingWide; ++u)
+        best = fminf(best, (t0 + u < total) ? sq_dist(qx, qy, v[u].x, v[u].y) : INFINITY);
+    }
   }
   const double Ld = (double)L;
   const int rmax = M.div_x > M.div_y ? M.div_x : M.div_y;
@@ -95,7 +139,7 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
       if (yy == y0 || yy == y1) {
         int xa = x0 > cx - hw ? x0 : cx - hw, xb = x1 < cx + hw ? x1 : cx + hw;
         xa = xa < 0 ? 0 : xa; xb = xb >= M.div_x ? M.div_x - 1 : xb;
-        if (xa <= xb) { const int sa = row[xa], sb = row[xb + 1]; best = scan_bucket(M.pts, sa, sb, qx, qy, best); }
+        if (xa <= xb) { const int sa = gld_i(row + xa), sb = gld_i(row + xb + 1); best = scan_bucket(M.pts, sa, sb, qx, qy, best); }
       } else if (R <= hw) {
         I2u a = {0, 0}, b = {0, 0};                     // both voxels' offsets in flight together
         if (x0 >= 0) a = ld_i2u(row + x0);
@@ -106,4 +150,8 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
     }
   }
   return best;
+}
+
+__device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy) {
+  return nearest_finish(M, qx, qy, nearest_prep(M, qx, qy));
 }

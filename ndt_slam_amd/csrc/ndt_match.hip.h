@@ -52,6 +52,14 @@ constexpr unsigned long long kWatchTicks = 400000000ull;   // ~4 s of the 100 MH
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
+// Phase timers of the match kernel exist only in diagnostic builds (-DNDT_DIAG): a dozen 64-bit running sums live
+// across every loop of the kernel cost registers the pass loop needs.
+#ifdef NDT_DIAG
+constexpr bool kProf = true;
+#else
+constexpr bool kProf = false;
+#endif
+
 // Per-scan control block: four 128-byte lines, so that the words touched by different parties
 // (epoch polls / arrivals / attach + ready counts / pose reads) never share a line.
 //
@@ -123,8 +131,17 @@ struct Lds {
   int jnext, stop;                 // units of the open segment handed out so far; close the segment
   unsigned diag[2];                // diagnostic: ticks of fill_window's first two phases
   int clipped;                     // owner: the scan's voxel bounding box did not fit the window
+  // what a pass needs besides PP and RG, read by pass_units (a separate function: see there)
+  MapView M;                       // copy of the kernel argument
+  const float2 *pts;               // the scan as the passes read it (ordered scratch copy, or the input)
+  int npts;
   double etab[64];
 };
+
+// The match kernel's LDS lives at namespace scope so that pass_units -- deliberately NOT inlined into the kernel --
+// can reach it by name: the window pool (slot table + voxel records of one scan) and the control / scratch block.
+__shared__ Lds g_L;
+__shared__ uint4 g_pool[kPoolBytes / 16];
 
 __device__ __forceinline__ Window window_of(const Region &R, const uint4 *pool) {
   Window W;
@@ -199,7 +216,7 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
   const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
   unsigned short *slot = reinterpret_cast<unsigned short *>(pool);
   CellEntry *ent = reinterpret_cast<CellEntry *>(reinterpret_cast<char *>(pool) + ((r.rw * r.rh * 2 + 15) / 16) * 16);
-  const u64 t_fill0 = wall_clock64();
+  const u64 t_fill0 = kProf ? wall_clock64() : 0;
   const int ncell = r.rw * r.rh;
   const int rounds = (ncell + kBlock - 1) / kBlock;          // <= kRegionCells / kBlock = 16
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -259,7 +276,7 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
   __syncthreads();
   if (threadIdx.x < kWords) dx[threadIdx.x] = kword;        // = keepw, two words per ballot word
   __syncthreads();
-  if (threadIdx.x == 0) L.diag[0] = (unsigned)(wall_clock64() - t_fill0);
+  if (kProf && threadIdx.x == 0) L.diag[0] = (unsigned)(wall_clock64() - t_fill0);
   // exclusive prefix of the kept counts over the rounds * kWaves ballot words (cell order)
   const int nword = rounds * kWaves;                           // <= 256
   if (threadIdx.x < 256) {
@@ -288,7 +305,7 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
     z.cent = make_float2(-INFINITY, -INFINITY);
     ent[r.cap + 1] = z;                         // occupied voxels without an LDS record
     L.RG.nspill = skipped + (kept > r.cap ? kept - r.cap : 0);
-    L.diag[1] = (unsigned)(wall_clock64() - t_fill0);
+    if (kProf) L.diag[1] = (unsigned)(wall_clock64() - t_fill0);
   }
   __syncthreads();
   for (int j0 = 0; j0 < rounds; j0 += 4) {                   // four rounds' record loads in flight together
@@ -479,10 +496,41 @@ __device__ __forceinline__ double uniform_d(double v) {
   return __longlong_as_double((long long)(((u64)hi << 32) | lo));
 }
 
+__device__ __forceinline__ unsigned uniform_u(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+template <typename T>
+__device__ __forceinline__ const T *uniform_p(const T *p) {
+  const u64 b = (u64)p;
+  return (const T *)(((u64)uniform_u((unsigned)(b >> 32)) << 32) | uniform_u((unsigned)b));
+}
+
+// NOT inlined: the pass loop needs the register file to itself.  Inlined into the kernel (three call sites, each with
+// the LDS and the HBM path of eval_point) it inherited everything the persistent kernel keeps alive around it and the
+// compiler spilled inside the point loop (a dozen scratch reloads per point, each behind an s_waitcnt vmcnt(0)).  As a
+// function of its own it is allocated on its own: its inputs come from LDS (g_L.M, g_L.RG, g_L.PP, g_L.pts) and are
+// moved to SGPRs once per call.
 template <bool SSE, bool INCL>
-__device__ __forceinline__ void unit_sums(const MapView &M, const Window &W, const double *__restrict__ etab,
-                                          const PassPose &pp_in, const float2 *__restrict__ pts, int n, int w,
-                                          int q0, int q1, double *__restrict__ dst, int dst_stride) {
+__device__ __noinline__ void pass_units(int w_in, int q0_in, int q1_in, double *__restrict__ dst, int dst_stride_in) {
+  const int w = (int)uniform_u((unsigned)w_in), q0 = (int)uniform_u((unsigned)q0_in), q1 = (int)uniform_u((unsigned)q1_in);
+  const int dst_stride = (int)uniform_u((unsigned)dst_stride_in);
+  const Lds &L = g_L;
+  MapView M;
+  M.inv_leaf = uniform_f(L.M.inv_leaf); M.leaf = uniform_f(L.M.leaf); M.r2 = uniform_f(L.M.r2);
+  M.radius_inclusive = INCL; M.transform_sse = SSE;
+  M.min_bx = (int)uniform_u((unsigned)L.M.min_bx); M.min_by = (int)uniform_u((unsigned)L.M.min_by);
+  M.div_x = (int)uniform_u((unsigned)L.M.div_x); M.div_y = (int)uniform_u((unsigned)L.M.div_y);
+  M.gw = (int)uniform_u((unsigned)L.M.gw); M.gh = (int)uniform_u((unsigned)L.M.gh);
+  M.cent = uniform_p(L.M.cent); M.rec = uniform_p(L.M.rec); M.occ = uniform_p(L.M.occ);
+  M.pt_start = uniform_p(L.M.pt_start); M.pts = uniform_p(L.M.pts);
+  M.d1 = uniform_d(L.M.d1); M.d2 = uniform_d(L.M.d2);
+  Region R;
+  R.x0 = (int)uniform_u((unsigned)L.RG.x0); R.y0 = (int)uniform_u((unsigned)L.RG.y0);
+  R.rw = (int)uniform_u((unsigned)L.RG.rw); R.rh = (int)uniform_u((unsigned)L.RG.rh);
+  R.cap = (int)uniform_u((unsigned)L.RG.cap); R.nspill = (int)uniform_u((unsigned)L.RG.nspill);
+  const Window W = window_of(R, g_pool);
+  const double *__restrict__ etab = L.etab;
+  const PassPose &pp_in = L.PP;
+  const float2 *__restrict__ pts = uniform_p(L.pts);
+  const int n = (int)uniform_u((unsigned)L.npts);
   PassPose pp;
   pp.T.c = uniform_f(pp_in.T.c); pp.T.s = uniform_f(pp_in.T.s); pp.T.tx = uniform_f(pp_in.T.tx); pp.T.ty = uniform_f(pp_in.T.ty);
   pp.cj = uniform_d(pp_in.cj); pp.sj = uniform_d(pp_in.sj); pp.ch = uniform_d(pp_in.ch); pp.sh = uniform_d(pp_in.sh);
@@ -494,11 +542,11 @@ __device__ __forceinline__ void unit_sums(const MapView &M, const Window &W, con
   const int base = w * 64 + lane;
   if (pp.kind == 0) {
     Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
-    float2 p0 = pts[min(base + kbeg * kBlock, last)], p1 = pts[min(base + (kbeg + 1) * kBlock, last)];
+    float2 p0 = gld_f2(pts + min(base + kbeg * kBlock, last)), p1 = gld_f2(pts + min(base + (kbeg + 1) * kBlock, last));
     int q = q0, kb = min(per_lane, (q0 + 1) * run);        // end of the current run
 #pragma nounroll
     for (int k = kbeg; k < kend; ++k) {
-      const float2 p2 = pts[min(base + (k + 2) * kBlock, last)];
+      const float2 p2 = gld_f2(pts + min(base + (k + 2) * kBlock, last));
       if (base + k * kBlock >= n) p0.x = NAN;              // past the end: contributes nothing
       eval_point<SSE, INCL>(M, W, etab, pp.T, p0.x, p0.y, pp.cj, pp.sj, pp.ch, pp.sh, A);
       p0 = p1; p1 = p2;
@@ -516,15 +564,28 @@ __device__ __forceinline__ void unit_sums(const MapView &M, const Window &W, con
     for (int q = q0; q < q1; ++q) {
       const int k0 = min(per_lane, q * run), k1 = min(per_lane, (q + 1) * run);
       double fsum = 0.0, fcnt = 0.0;
-      for (int k = k0; k < k1; ++k) {
-        const int i = base + k * kBlock;
-        if (i >= n) break;
-        const float2 pt = pts[i];
-        float qx, qy;
+      // software pipeline: the offsets load of point k + 1 is in flight while the buckets of point k are read
+      // (lanes past the end of the scan search for a copy of its last point and drop the result)
+      float qx, qy;
+      {
+        const float2 pt = gld_f2(pts + min(base + k0 * kBlock, last));
         tf_apply_t<SSE>(pp.T, pt.x, pt.y, qx, qy);
-        if (!finite2(qx, qy)) continue;
-        const float best = nearest_sq(M, qx, qy);
-        if (best < INFINITY) { fsum += (double)best; fcnt += 1.0; }
+      }
+      bool ok = (k0 < k1) && (base + k0 * kBlock < n) && finite2(qx, qy);
+      NearPrep P = nearest_prep(M, ok ? qx : 0.f, ok ? qy : 0.f);
+      for (int k = k0; k < k1; ++k) {
+        float nx, ny;
+        {
+          const float2 pt = gld_f2(pts + min(base + (k + 1) * kBlock, last));
+          tf_apply_t<SSE>(pp.T, pt.x, pt.y, nx, ny);
+        }
+        const bool nok = (k + 1 < k1) && (base + (k + 1) * kBlock < n) && finite2(nx, ny);
+        const NearPrep PN = nearest_prep(M, nok ? nx : 0.f, nok ? ny : 0.f);
+        if (ok) {
+          const float best = nearest_finish(M, qx, qy, P);
+          if (best < INFINITY) { fsum += (double)best; fcnt += 1.0; }
+        }
+        qx = nx; qy = ny; ok = nok; P = PN;
       }
       fsum = wave_sum(fsum); fcnt = wave_sum(fcnt);
       if (lane == 0) { dst[(q - q0) * dst_stride] = fsum; dst[(q - q0) * dst_stride + 1] = fcnt; }
@@ -556,16 +617,17 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
                  unsigned char *__restrict__ ws /* WsHeader, ScanCtl[B], unit totals[B][kUnits][12], marked-cell bitmaps[B][kRegionCells/32] */,
                  int allow_helpers /* 0: none; else max helper workgroups per scan */,
                  unsigned long long *__restrict__ prof /* diagnostic: 8 words per scan */) {
-  __shared__ Lds L;
-  __shared__ uint4 pool[kPoolBytes / 16];
+  Lds &L = g_L;
+  uint4 *const pool = g_pool;
   WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
   ScanCtl *ctl = reinterpret_cast<ScanCtl *>(ws + sizeof(WsHeader));
   u64 *utot = reinterpret_cast<u64 *>(ws + sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl));
   unsigned *wantmap = reinterpret_cast<unsigned *>(ws + sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl) +
                                                   (size_t)B * kUnits * 12 * sizeof(double));
-  const u64 t_start = wall_clock64();
+  const u64 t_start = kProf ? wall_clock64() : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 64) L.etab[threadIdx.x] = c_exp2_tab[threadIdx.x];
+  if (threadIdx.x == 64) L.M = M;
   bool aborted = false;
 
   // =========================== owner of scans blockIdx.x, + gridDim.x, ... ===========================
@@ -588,13 +650,13 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     __syncthreads();
     const float2 *pts = scan;
     if (n > 0) {
-      const u64 q0 = wall_clock64();
+      const u64 q0 = kProf ? wall_clock64() : 0;
       compute_region<SSE>(M, L.S.T, scan, n, L);
-      const u64 q1 = wall_clock64();
+      const u64 q1 = kProf ? wall_clock64() : 0;
       // scratch copy: at the scan's own offsets, or (every match uses scan 0) one slot per workgroup
       float2 *sp = sorted ? (shared_scan ? sorted + (size_t)blockIdx.x * (size_t)n : sorted + o0) : nullptr;
       if (sort_points<SSE>(M, L.S.T, scan, n, L, pool, sp)) pts = sp;
-      const u64 q2 = wall_clock64();
+      const u64 q2 = kProf ? wall_clock64() : 0;
       if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
         const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
         unsigned *gw = wantmap + (size_t)b * (kRegionCells / 32);
@@ -619,24 +681,22 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         }
       }
       fill_window(M, L, pool);
-      const u64 q3 = wall_clock64();
-      if (prof && threadIdx.x == 0) {
-        const u64 q4 = wall_clock64();
+      const u64 q3 = kProf ? wall_clock64() : 0;
+      if (kProf && prof && threadIdx.x == 0) {
         prof[8 * (size_t)B + 8 * (size_t)b + 6] = ((q1 - q0) << 32) | ((q2 - q1) & 0xFFFFFFFFull);
         prof[8 * (size_t)B + 8 * (size_t)b + 7] = ((q3 - q2) << 32) | ((u64)(L.diag[0] & 0xFFFFu) << 16) | (u64)(L.diag[1] & 0xFFFFu);
       }
     }
-    const Window W = window_of(L.RG, pool);
-    if (threadIdx.x == 0) L.sflag[1] = 0;            // registered helpers (refreshed during every advance)
+    if (threadIdx.x == 0) { L.sflag[1] = 0; L.pts = pts; L.npts = n; }   // sflag[1]: registered helpers (refreshed during every advance)
     unsigned epoch = 1;
     u64 t_eval = 0, t_adv = 0, tt0 = 0, tt1 = 0, t_wait = 0, t_first_shared = 0, t_fit = 0;
     u64 ts1 = 0, ts2 = 0, ts3 = 0, a_pro = 0, a_own = 0, a_wait = 0, a_comb = 0, a_adv = 0, a_n = 0;   // shared derivative passes (diagnostic)
-    const u64 t_scan0 = wall_clock64() - t_start;
+    const u64 t_scan0 = kProf ? wall_clock64() - t_start : 0;
     unsigned n_shared = 0, n_helped = 0;
     bool fitness_done = false;
     // ---- passes: derivative passes until the optimiser stops, then one fitness pass ----
     while (n > 0 && !fitness_done) {
-      if (prof) tt0 = wall_clock64();
+      if (kProf && prof) tt0 = wall_clock64();
       const bool fit_pass = (L.S.phase == PH_DONE);
       // A pass is run as one or more SEGMENTS of consecutive units.  A derivative pass is one segment:
       // solo (one walk per wave) or split over the registered helpers.  The fitness pass runs once, can
@@ -672,13 +732,12 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
           }
         }
         __syncthreads();
-        if (prof) ts1 = wall_clock64();
+        if (kProf && prof) ts1 = wall_clock64();
         const int nhelp = L.sflag[0];
-        const PassPose pp = L.PP;
         int uend = kUnits;
         if (nhelp <= 0 && !fit_pass) {
           // solo derivative pass: wave w computes its own units (w, 0..kSub-1) in one walk
-          unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, wave, 0, kSub, L.wpart + wave * 12, kWaves * 12);
+          pass_units<SSE, INCL>(wave, 0, kSub, L.wpart + wave * 12, kWaves * 12);
         } else {
           // this workgroup's units ubeg + j*(nhelp+1), j = 0, 1, ... handed to its waves from an LDS counter
           const bool watch = fit_pass && nhelp == 0 && allow_helpers;
@@ -689,7 +748,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
             j = __builtin_amdgcn_readfirstlane(j);
             const int u = ubeg + j * (nhelp + 1);
             if (u >= kUnits) break;
-            unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, u % kWaves, u / kWaves, u / kWaves + 1, L.wpart + u * 12, 0);
+            pass_units<SSE, INCL>(u % kWaves, u / kWaves, u / kWaves + 1, L.wpart + u * 12, 0);
             if (watch && wave == kWaves - 1 && lane == 0) {
               // one wave looks for a registered helper between its units.  (Raising the scan's priority
               // when this pass runs long was tried: it draws helpers away from the scans that still have
@@ -706,7 +765,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
           ++epoch;
           pass_h = nhelp;
           __syncthreads();
-          if (prof) ts2 = wall_clock64();
+          if (kProf && prof) ts2 = wall_clock64();
           // wait for the helpers' units (every counted helper is polling the epoch word or computing)
           if (threadIdx.x == 0) {
             const int total = kUnits - ubeg;
@@ -718,13 +777,11 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
               if (watchdog(hdr, w0, polls)) { bad = 1; break; }
               __builtin_amdgcn_s_sleep(2);
             }
-            t_wait += wall_clock64() - w0;
-            if (n_shared == 0) t_first_shared = w0 - t_start;
-            n_shared += 1; n_helped += need;
+            if (kProf) { t_wait += wall_clock64() - w0; if (n_shared == 0) t_first_shared = w0 - t_start; n_shared += 1; n_helped += need; }
             L.sflag[2] = bad;
           }
           __syncthreads();
-          if (prof) ts3 = wall_clock64();
+          if (kProf && prof) ts3 = wall_clock64();
           if (L.sflag[2]) { aborted = true; break; }
           // helpers' totals of this segment: one load per lane, in flight together
           if (threadIdx.x < (kUnits - ubeg) * 12) {
@@ -751,14 +808,14 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (prof) { tt1 = wall_clock64(); }
+        if (kProf && prof) { tt1 = wall_clock64(); }
         if (!fit_pass && lane == 0) advance(L.S, P, M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
       }
       // meanwhile another wave fetches the number of registered helpers for the next pass
       if (!fit_pass && threadIdx.x == 64 && allow_helpers) L.sflag[1] = (int)rd32_fresh(&C->ready);
       if (fit_pass) fitness_done = true;
       __syncthreads();
-      if (prof) {
+      if (kProf && prof) {
         const u64 te = wall_clock64();
         if (threadIdx.x >= 64) tt1 = te;          // (only wave 0 stamps the end of the summation)
         t_eval += tt1 - tt0; if (fit_pass) t_fit = tt1 - tt0;
@@ -792,7 +849,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         st64(&C->ticket, (u64)kEpochDone << 32);
         __hip_atomic_fetch_add(&hdr->done, 1u, NDT_RLX, NDT_AGENT);
       }
-      if (prof) {
+      if (kProf && prof) {
         prof[8 * b + 0] = t_eval; prof[8 * b + 1] = t_adv | (t_fit << 32) | ((u64)(L.RG.nspill > 0) << 63); prof[8 * b + 2] = (t_first_shared << 32) | (t_scan0 & 0xFFFFFFFFull);
         prof[8 * b + 3] = (unsigned long long)S.evals | ((u64)n_shared << 16) | ((u64)n_helped << 32);
         prof[8 * b + 6] = t_wait; prof[8 * b + 7] = wall_clock64() - t_start;
@@ -847,7 +904,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         } else {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // geometry + ordered copy of the owner
           drain_vmem();
-          if (prof && h == 0) prof[8 * b + 4] = wall_clock64() - t_start;
+          if (kProf && prof && h == 0) prof[8 * b + 4] = wall_clock64() - t_start;
           code = b;
         }
       }
@@ -886,8 +943,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     const float2 *pts = L.sflag[1] ? (shared_scan ? sorted + (size_t)owner_wg * (size_t)n : sorted + o0)
                                    : (reinterpret_cast<const float2 *>(scans) + o0);
     if (L.sflag[2] == 0) fill_window(M, L, pool);          // a scan in its fitness pass needs no window
-    const Window W = window_of(L.RG, pool);
-    if (prof && threadIdx.x == 0 && prof[8 * vb + 5] == 0) prof[8 * vb + 5] = wall_clock64() - t_start;
+    if (threadIdx.x == 0) { L.pts = pts; L.npts = n; }
+    if (kProf && prof && threadIdx.x == 0 && prof[8 * vb + 5] == 0) prof[8 * vb + 5] = wall_clock64() - t_start;
     u64 *vtot = utot + (size_t)vb * kUnits * 12;
     // register: from now on this workgroup does nothing but watch the scan's epoch word
     if (threadIdx.x == 0) L.hrank = (int)__hip_atomic_fetch_add(&C->ready, 1u, NDT_RLX, NDT_AGENT);
@@ -910,7 +967,20 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         }
         word = wave_bcast64(word);
         const int h = (int)((word >> 16) & 0xFFu);
-        if ((u32)(word >> 32) != kEpochDone && rank < h && lane < 6) L.hpose[lane] = ld64(&C->pose[lane]);   // stable: this helper is counted in
+        if ((u32)(word >> 32) != kEpochDone && rank < h) {   // the pose block is stable: this helper is counted in
+          u64 pw = 0;
+          if (lane < 6) pw = ld64(&C->pose[lane]);
+          const u64 w0 = __shfl(pw, 0), w1 = __shfl(pw, 1);
+          if (lane == 0) {
+            PassPose q;
+            q.T.c = __uint_as_float((u32)w0); q.T.s = __uint_as_float((u32)(w0 >> 32));
+            q.T.tx = __uint_as_float((u32)w1); q.T.ty = __uint_as_float((u32)(w1 >> 32));
+            q.cj = 0; q.sj = 0; q.ch = 0; q.sh = 0;
+            q.kind = (int)((word >> 24) & 0xFFu);
+            L.PP.T = q.T; L.PP.kind = q.kind;
+          }
+          if (lane >= 2 && lane < 6) (&L.PP.cj)[lane - 2] = __longlong_as_double((long long)pw);   // cj, sj, ch, sh
+        }
         if (lane == 0) { L.hword = word; L.jnext = 0; }
       }
       __syncthreads();
@@ -921,13 +991,6 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       const int h = (int)((word >> 16) & 0xFFu), ubeg = (int)(word & 0xFFu), uend = (int)((word >> 8) & 0xFFu);
       int done_units = 0;
       if (rank < h) {
-        PassPose pp;
-        const u64 w0 = L.hpose[0], w1 = L.hpose[1];
-        pp.T.c = __uint_as_float((u32)w0); pp.T.s = __uint_as_float((u32)(w0 >> 32));
-        pp.T.tx = __uint_as_float((u32)w1); pp.T.ty = __uint_as_float((u32)(w1 >> 32));
-        pp.cj = __longlong_as_double((long long)L.hpose[2]); pp.sj = __longlong_as_double((long long)L.hpose[3]);
-        pp.ch = __longlong_as_double((long long)L.hpose[4]); pp.sh = __longlong_as_double((long long)L.hpose[5]);
-        pp.kind = (int)((word >> 24) & 0xFFu);
         double *wt = L.wtmp + wave * 12;
         for (int it = 0; it <= kUnits; ++it) {               // this workgroup's units, handed out from an LDS counter
           int j = 0;
@@ -935,7 +998,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
           j = __builtin_amdgcn_readfirstlane(j);
           const int u = ubeg + (rank + 1) + j * (h + 1);
           if (u >= uend) break;
-          unit_sums<SSE, INCL>(M, W, L.etab, pp, pts, n, u % kWaves, u / kWaves, u / kWaves + 1, wt, 0);
+          pass_units<SSE, INCL>(u % kWaves, u / kWaves, u / kWaves + 1, wt, 0);
           if (lane < 12) st64(&vtot[u * 12 + lane], (u64)__double_as_longlong(wt[lane]));
         }
         drain_vmem();                                        // the whole wave: its stores have landed

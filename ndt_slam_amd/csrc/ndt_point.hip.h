@@ -65,56 +65,55 @@ struct CellRec { double mx, my, i00, i01, i11; };
 __device__ __forceinline__ CellRec load_rec_global(const MapView &M, size_t base, int k) {
   const int r = (k * 11) >> 5, q = k - 3 * r;                 // k / 3 for k in [0, 9)
   const double *rec = M.rec + (base + (size_t)(r * M.gw + q)) * 8;
-  const double2 a = *reinterpret_cast<const double2 *>(rec);
-  const double2 b = *reinterpret_cast<const double2 *>(rec + 2);
-  CellRec c; c.mx = a.x; c.my = a.y; c.i00 = b.x; c.i01 = b.y; c.i11 = rec[4];
+  const double2 a = gld_d2(rec);
+  const double2 b = gld_d2(rec + 2);
+  CellRec c; c.mx = a.x; c.my = a.y; c.i00 = b.x; c.i01 = b.y; c.i11 = gld_d(rec + 4);
   return c;
 }
 
-struct PointTerms { double XT, YT, jx, jy, hx, hy; };
+// Sums over the in-radius voxels of ONE point.  With J = dT/dp = [e_x, e_y, j] (j the yaw column, a function of
+// the point only) everything a pair adds to the gradient and the Hessian is a product of point-only terms with
+//   se = sum e,   a = sum e u,   B = sum e (Sigma^-1 - d2 u u^T),   u = Sigma^-1 q,  e = exp(-d2/2 q^T u)
+// (eqs 6.12 / 6.13 restricted to (tx, ty, yaw): g = [a, a.j], H = [[B, B j], [., j^T B j + a.h]]), so the pair loop
+// only accumulates these six numbers and the point's contribution is formed once, after the loop.
+struct PointAcc { double se, a0, a1, b00, b01, b11; };
 
-__device__ __forceinline__ PointTerms point_terms(float x, float y, float xt, float yt, double cj,
-                                                  double sj, double ch, double sh) {
-  // yaw column of J_E and the (yaw,yaw) block of H_E (untransformed coordinates)
-  const double X = (double)x, Y = (double)y;
-  PointTerms P;
-  P.jx = X * (-sj) + Y * (-cj);
-  P.jy = X * cj + Y * (-sj);
-  P.hx = X * (-ch) + Y * sh;
-  P.hy = X * (-sh) + Y * (-ch);
-  P.XT = (double)xt; P.YT = (double)yt;
-  return P;
-}
-
-// one (point, voxel) pair: eqs 6.9 / 6.12 / 6.13 restricted to (tx, ty, yaw)
-__device__ __forceinline__ void accumulate_cell(double d2, const double *__restrict__ etab,
-                                                const PointTerms &P, const CellRec &c, Acc &A) {
-  const double nd2 = -d2;
-  const double q0 = P.XT - c.mx, q1 = P.YT - c.my;
+// one (point, voxel) pair
+__device__ __forceinline__ void accumulate_pair(double d2, double nd2, double nd2h, const double *__restrict__ etab,
+                                                double XT, double YT, const CellRec &c, PointAcc &S) {
+  const double q0 = XT - c.mx, q1 = YT - c.my;
   const double u0 = __builtin_fma(c.i01, q1, c.i00 * q0);      // Sigma^-1 q
   const double u1 = __builtin_fma(c.i11, q1, c.i01 * q0);
   const double m = __builtin_fma(q1, u1, q0 * u0);
-  double e = exp_neg(nd2 * m * 0.5, etab);
+  double e = exp_neg(nd2h * m, etab);                          // (-d2 m) / 2, the halving is exact
   const double e2 = d2 * e;
   if (e2 > 1.0 || e2 < 0.0) e = 0.0;                           // updateDerivatives error check
-  const double at = __builtin_fma(u1, P.jy, u0 * P.jx);        // q^T Sigma^-1 dT/dyaw
-  const double cx = __builtin_fma(c.i01, P.jy, c.i00 * P.jx);  // Sigma^-1 dT/dyaw
-  const double cy = __builtin_fma(c.i11, P.jy, c.i01 * P.jx);
-  const double v0 = nd2 * u0, v1 = nd2 * u1, vt = nd2 * at;
-  A.e += e;
-  A.g0 = __builtin_fma(e, u0, A.g0);
-  A.g1 = __builtin_fma(e, u1, A.g1);
-  A.g2 = __builtin_fma(e, at, A.g2);
-  A.hxx = __builtin_fma(e, __builtin_fma(v0, u0, c.i00), A.hxx);
-  A.hxy = __builtin_fma(e, __builtin_fma(v0, u1, c.i01), A.hxy);
-  A.hxt = __builtin_fma(e, __builtin_fma(v0, at, cx), A.hxt);
-  A.hyy = __builtin_fma(e, __builtin_fma(v1, u1, c.i11), A.hyy);
-  A.hyt = __builtin_fma(e, __builtin_fma(v1, at, cy), A.hyt);
-  double tt = __builtin_fma(P.jx, cx, P.jy * cy);              // J^T Sigma^-1 J
-  tt = __builtin_fma(u0, P.hx, tt);                            // + q^T Sigma^-1 d2T/dyaw2
-  tt = __builtin_fma(u1, P.hy, tt);
-  tt = __builtin_fma(vt, at, tt);
-  A.htt = __builtin_fma(e, tt, A.htt);
+  const double v0 = nd2 * u0, v1 = nd2 * u1;
+  S.se += e;
+  S.a0 = __builtin_fma(e, u0, S.a0);
+  S.a1 = __builtin_fma(e, u1, S.a1);
+  S.b00 = __builtin_fma(e, __builtin_fma(v0, u0, c.i00), S.b00);
+  S.b01 = __builtin_fma(e, __builtin_fma(v0, u1, c.i01), S.b01);
+  S.b11 = __builtin_fma(e, __builtin_fma(v1, u1, c.i11), S.b11);
+}
+
+// the point's terms: yaw column of J_E and the (yaw,yaw) block of H_E (untransformed coordinates)
+__device__ __forceinline__ void finish_point(float x, float y, double cj, double sj, double ch, double sh,
+                                             const PointAcc &S, Acc &A) {
+  const double X = (double)x, Y = (double)y;
+  const double jx = X * (-sj) + Y * (-cj), jy = X * cj + Y * (-sj);
+  const double hx = X * (-ch) + Y * sh, hy = X * (-sh) + Y * (-ch);
+  const double bx = __builtin_fma(S.b01, jy, S.b00 * jx);      // B j
+  const double by = __builtin_fma(S.b11, jy, S.b01 * jx);
+  double tt = __builtin_fma(jx, bx, jy * by);                  // j^T B j
+  tt = __builtin_fma(S.a0, hx, tt);                            // + a . d2T/dyaw2
+  tt = __builtin_fma(S.a1, hy, tt);
+  A.e += S.se;
+  A.g0 += S.a0; A.g1 += S.a1;
+  A.g2 += __builtin_fma(S.a1, jy, S.a0 * jx);
+  A.hxx += S.b00; A.hxy += S.b01; A.hyy += S.b11;
+  A.hxt += bx; A.hyt += by;
+  A.htt += tt;
 }
 
 // Everything one source point contributes to a derivative pass.
@@ -148,10 +147,12 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
       lowx = fminf(lowx, cc.x);
       mask |= in_radius<INCL>(M.r2, xt, yt, cc) << (r * 3 + q);
     }
+  const double nd2 = -M.d2, nd2h = nd2 * 0.5;
   if (inwin & (lowx != -INFINITY)) {
     if (!mask) return;
     A.pairs += __builtin_popcount(mask);
-    const PointTerms P = point_terms(x, y, xt, yt, cj, sj, ch, sh);
+    const double XT = (double)xt, YT = (double)yt;
+    PointAcc S = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma nounroll
     do {
       const int k = __builtin_ctz(mask);
@@ -159,8 +160,9 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
       const int r = (k * 11) >> 5, q = k - 3 * r;
       const CellEntry &E = W.ent[srow[r * R.rw + q]];
       CellRec c; c.mx = E.mx; c.my = E.my; c.i00 = E.i00; c.i01 = E.i01; c.i11 = E.i11;
-      accumulate_cell(M.d2, etab, P, c, A);
+      accumulate_pair(M.d2, nd2, nd2h, etab, XT, YT, c, S);
     } while (mask);
+    finish_point(x, y, cj, sj, ch, sh, S, A);
     return;
   }
   if (!ingrid) return;
@@ -171,16 +173,18 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) mask |= in_radius<INCL>(M.r2, xt, yt, grow[r * M.gw + q]) << (r * 3 + q);
+    for (int q = 0; q < 3; ++q) mask |= in_radius<INCL>(M.r2, xt, yt, gld_f2(grow + (r * M.gw + q))) << (r * 3 + q);
   if (!mask) return;
   A.pairs += __builtin_popcount(mask);
-  const PointTerms P = point_terms(x, y, xt, yt, cj, sj, ch, sh);
+  const double XT = (double)xt, YT = (double)yt;
+  PointAcc S = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma nounroll
   do {
     const int k = __builtin_ctz(mask);
     mask &= mask - 1;
-    accumulate_cell(M.d2, etab, P, load_rec_global(M, base, k), A);
+    accumulate_pair(M.d2, nd2, nd2h, etab, XT, YT, load_rec_global(M, base, k), S);
   } while (mask);
+  finish_point(x, y, cj, sj, ch, sh, S, A);
 }
 
 // Fixed-order sums over the workgroup: lanes by shuffle, waves through LDS in wave order.

@@ -27,36 +27,44 @@ def shard_batch(scans, offsets, inits, world, rank):
 
 
 def scatter_batch(scans, offsets, inits, src=0, device="cpu"):
-    """Rank `src` holds the batch (numpy arrays); every rank returns its own shard as numpy arrays.
-    Point-to-point sends of exactly the shard bytes (on xGMI the root fans out over its links)."""
+    """Rank `src` holds the batch (numpy arrays; None elsewhere); every rank returns its own shard as TENSORS on
+    `device` -- (scans [n, 2] float32, offsets [b + 1] int64 rebased to 0, inits [b, 3] float64) -- ready to be
+    handed to ndt_align_batch_dev by data_ptr().  The shards travel as grouped point-to-point sends of exactly the
+    shard bytes (RCCL over xGMI on the GPU box: the root fans out over its links; no host round trip on the
+    receiving side); gloo on CPU tensors in the tests."""
     world, rank = dist.get_world_size(), dist.get_rank()
+    device = torch.device(device)
     meta = [None]
     if rank == src:
-        meta[0] = [(int(offsets[shard_bounds(len(inits), world, r)[0]]),
-                    int(offsets[shard_bounds(len(inits), world, r)[1]]),
-                    shard_bounds(len(inits), world, r)) for r in range(world)]
+        cuts = [shard_bounds(len(inits), world, r) for r in range(world)]
+        meta[0] = [(int(offsets[lo]), int(offsets[hi]), (lo, hi)) for lo, hi in cuts]
     dist.broadcast_object_list(meta, src=src)
     p0, p1, (lo, hi) = meta[0][rank]
     nb = hi - lo
     if rank == src:
-        reqs = []
+        ops, keep = [], []
         for r in range(world):
             if r == src:
                 continue
             q0, q1, (l, h) = meta[0][r]
-            pay = [torch.from_numpy(np.ascontiguousarray(scans[q0:q1])).to(device),
-                   torch.from_numpy((offsets[l:h + 1] - offsets[l]).astype(np.int64)).to(device),
-                   torch.from_numpy(np.ascontiguousarray(inits[l:h])).to(device)]
-            reqs += [dist.isend(t, dst=r) for t in pay]
-        for q in reqs:
-            q.wait()
-        return shard_batch(scans, offsets, inits, world, rank)
+            pay = [torch.from_numpy(np.ascontiguousarray(scans[q0:q1], dtype=np.float32)).to(device),
+                   torch.from_numpy((np.asarray(offsets[l:h + 1]).astype(np.int64) - int(offsets[l]))).to(device),
+                   torch.from_numpy(np.ascontiguousarray(inits[l:h], dtype=np.float64)).to(device)]
+            keep += pay
+            ops += [dist.P2POp(dist.isend, t, r) for t in pay]
+        if ops:
+            for q in dist.batch_isend_irecv(ops):
+                q.wait()
+        sc, of, ini = shard_batch(scans, offsets, inits, world, rank)
+        return (torch.from_numpy(np.ascontiguousarray(sc, dtype=np.float32)).to(device),
+                torch.from_numpy(of.astype(np.int64)).to(device),
+                torch.from_numpy(np.ascontiguousarray(ini, dtype=np.float64)).to(device))
     t_sc = torch.empty((p1 - p0, 2), dtype=torch.float32, device=device)
     t_of = torch.empty(nb + 1, dtype=torch.int64, device=device)
     t_in = torch.empty((nb, 3), dtype=torch.float64, device=device)
-    for t in (t_sc, t_of, t_in):
-        dist.recv(t, src=src)
-    return t_sc.cpu().numpy(), t_of.cpu().numpy().astype(np.uint64), t_in.cpu().numpy()
+    for q in dist.batch_isend_irecv([dist.P2POp(dist.irecv, t, src) for t in (t_sc, t_of, t_in)]):
+        q.wait()
+    return t_sc, t_of, t_in
 
 
 _GATHER_OK = True
@@ -78,14 +86,24 @@ def gather_results(res_bytes, dst=0):
     return full if rank == dst else None
 
 
-def best_hypothesis(scores, first_index, device="cpu"):
-    """Arg-max of a score over all ranks' seeds: each rank passes its local scores and the global
-    index of its first seed; returns (best score, global index) on every rank."""
-    local = int(np.argmax(scores))
-    t = torch.tensor([float(scores[local])], dtype=torch.float64, device=device)
+def best_hypothesis_t(scores, global_index):
+    """Arg-max of a score over all ranks without leaving the device: `scores` a 1-D float64 tensor of this rank's
+    hypotheses, `global_index` the int64 tensor of their global numbers (ascending), both on the device the process
+    group communicates from.  Returns (best score, its global index) as 1-element tensors on every rank; ties go
+    to the lowest global index.  Two all-reduces of 8 bytes."""
+    best, k = torch.max(scores, dim=0)
+    t = best.reshape(1).clone()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    best = float(t.item())
-    cand = first_index + local if float(scores[local]) == best else np.iinfo(np.int64).max
-    i = torch.tensor([cand], dtype=torch.int64, device=device)
-    dist.all_reduce(i, op=dist.ReduceOp.MIN)       # ties: lowest global index
-    return best, int(i.item())
+    big = torch.full((1,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=scores.device)
+    cand = torch.where(best.reshape(1) == t, global_index[k].reshape(1), big)
+    dist.all_reduce(cand, op=dist.ReduceOp.MIN)
+    return t, cand
+
+
+def best_hypothesis(scores, first_index, device="cpu"):
+    """numpy front of best_hypothesis_t for a contiguous shard: local scores + the global index of its first seed;
+    returns (best score, global index) on every rank."""
+    sc = torch.from_numpy(np.ascontiguousarray(scores, dtype=np.float64)).to(device)
+    gi = torch.arange(first_index, first_index + len(scores), dtype=torch.int64, device=device)
+    t, i = best_hypothesis_t(sc, gi)
+    return float(t.item()), int(i.item())

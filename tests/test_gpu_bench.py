@@ -49,4 +49,32 @@ def test_two_rank_path_walks_through_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["scans_per_gpu"] == 256 and "x2" in d["config"]["parallelism"]
+    assert "scatter from rank 0" in d["config"]["parallelism"] and d["comm"]["scatter_ms"] > 0
+    assert len(d["per_rank"]["kernel_ms"]) == 2 and min(d["per_rank"]["kernel_ms"]) > 0
     assert "cpu_baseline" not in d                     # the CPU leg runs at N = 1 only
+
+
+def test_two_rank_multi_hypothesis_path_walks_through_on_one_gpu():
+    """configs[4] at N > 1 (scan broadcast, seeds sharded by stride, arg-max of the scores over the ranks) rehearsed
+    with both ranks on device 0 over gloo."""
+    env = dict(os.environ, NDT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29519", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "C5"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["matches_per_gpu"] == 512 and d["config"]["map_points"] == 5_000_000
+    g = d["best_hypothesis"]["global"]
+    assert g["trans_prob"] >= d["best_hypothesis"]["trans_prob"] and 0 <= g["seed"] < 4096
+
+
+def test_bench_c5_and_two_launches_in_flight():
+    """`--config C5` at N = 1 and `--inflight 2` (alternating contexts) keep the contract and the results."""
+    for extra in (["--config", "C5"], ["--inflight", "2"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--cpu-sample", "8",
+                              "--cpu-reps", "1", "--no-single-scan"] + extra, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+        assert d["parity"]["max_dpos_m"] <= 1e-4 and d["parity"]["max_dyaw_rad"] <= 1e-4 and d["parity"]["same_iters"]
+        assert 0 < d["roofline"]["frac"] < 1 and d["value"] > 0

@@ -46,12 +46,21 @@ def _worker(rank, world, port, outdir):
     else:
         scans = off = inits = None
     sc, of, ini = shard.scatter_batch(scans, off, inits, src=0)
+    assert isinstance(sc, torch.Tensor) and sc.dtype == torch.float32 and of.dtype == torch.int64 and ini.dtype == torch.float64
+    lo, hi = shard.shard_bounds(B, world, rank)
+    assert len(ini) == hi - lo and len(of) == hi - lo + 1 and int(of[0]) == 0 and int(of[-1]) == len(sc)
+    sc, of, ini = sc.numpy(), of.numpy().astype(np.uint64), ini.numpy()      # (device tensors on the GPU box: data_ptr())
     res = om.align_batch(sc, of, ini)
     pad = 4 - len(res)                                            # equal-size records for gather
     buf = np.zeros(4 * O.RESULT_DTYPE.itemsize, np.uint8)
     buf[:len(res) * O.RESULT_DTYPE.itemsize] = np.frombuffer(res.tobytes(), np.uint8)
     got = shard.gather_results(torch.from_numpy(buf), dst=0)
     best = shard.best_hypothesis(res["trans_prob"], shard.shard_bounds(B, world, rank)[0])
+    # configs[4] numbering: rank r holds every `world`-th hypothesis of a lattice (global index r + world * k)
+    lat = np.array([0.3, 0.9, 0.1, 0.9, 0.5, 0.2, 0.8, 0.4])        # 0.9 twice: the lower global index (1) must win
+    mine = torch.from_numpy(lat[rank::world].copy())
+    t, gi = shard.best_hypothesis_t(mine, rank + world * torch.arange(len(mine), dtype=torch.int64))
+    strided_ok = float(t.item()) == 0.9 and int(gi.item()) == 1
     if rank == 0:
         parts = []
         for r in range(world):
@@ -59,7 +68,7 @@ def _worker(rank, world, port, outdir):
             parts.append(np.frombuffer(got[r].numpy().tobytes(), O.RESULT_DTYPE)[:hi - lo])
         allres = np.concatenate(parts)
         ref = om.align_batch(scans, off, inits)
-        ok = allres.tobytes() == ref.tobytes() and best[1] == int(np.argmax(ref["trans_prob"]))
+        ok = allres.tobytes() == ref.tobytes() and best[1] == int(np.argmax(ref["trans_prob"])) and strided_ok
         open(os.path.join(outdir, "ok"), "w").write("1" if ok else "0")
     dist.barrier()
     dist.destroy_process_group()
