@@ -155,3 +155,79 @@ __device__ __forceinline__ float nearest_finish(const MapView &M, float qx, floa
 __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy) {
   return nearest_finish(M, qx, qy, nearest_prep(M, qx, qy));
 }
+
+// ------------------------------------------------------------------------------------------
+// a7 for a batch: getFitnessScore of every match (src/PoseEstimator.cpp:43), queued behind the match kernel.
+// Inside the match kernel (one 16-wave workgroup per CU, all registers taken) this search ran at the latency of
+// its dependent loads -- offsets, bucket, neighbouring buckets: ~110 us per 10k-point scan, a quarter of a match.
+// As a kernel of its own it runs at 8 waves per SIMD on the whole chip and is bound by the vector L1 instead.
+// Two steps so that the sum keeps ONE fixed order whatever the grid: the squared distance of every point (in the
+// order the passes read the scan: the cell-ordered copy, so that the lanes of a wave share buckets), then per match
+// the sum in the unit order of the passes (lane -> wave butterfly -> units 0..63).
+// ------------------------------------------------------------------------------------------
+#ifndef NDT_FIT_OCC
+#define NDT_FIT_OCC 6
+#endif
+template <bool SSE>
+__global__ void __launch_bounds__(256, NDT_FIT_OCC)
+fitness_points_kernel(MapView M, const float *__restrict__ scans, const unsigned long long *__restrict__ offsets, int B,
+                      int shared_scan, const float2 *__restrict__ sorted, const ndt_result *__restrict__ results,
+                      float *__restrict__ fit) {
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
+    const unsigned long long o1 = shared_scan ? offsets[1] : offsets[b + 1];
+    const int n = (int)(o1 - o0);
+    const ndt_result *R = results + b;
+    const Tf32 T = {R->T00, R->T10, R->T03, R->T13};
+    const bool use_sorted = sorted != nullptr && !(R->flags & NDT_FLAG_UNSORTED);
+    const size_t slot = shared_scan ? (size_t)b * (size_t)n : (size_t)o0;
+    const float2 *pts = use_sorted ? sorted + slot : reinterpret_cast<const float2 *>(scans) + o0;
+    float *out = fit + slot;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const float2 pt = pts[i];
+      float qx, qy;
+      tf_apply_t<SSE>(T, pt.x, pt.y, qx, qy);
+      out[i] = finite2(qx, qy) ? nearest_sq(M, qx, qy) : INFINITY;
+    }
+  }
+}
+
+constexpr int kFitBlock = 1024, kFitSub = 4;     // = kBlock, kSub of the match kernel: the order of the sum
+__global__ void __launch_bounds__(kFitBlock)
+fitness_reduce_kernel(const unsigned long long *__restrict__ offsets, int B, int shared_scan,
+                      const float *__restrict__ fit, ndt_result *__restrict__ results) {
+  __shared__ double U[kFitSub * (kFitBlock / 64) * 2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, base = wave * 64 + lane;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
+    const unsigned long long o1 = shared_scan ? offsets[1] : offsets[b + 1];
+    const int n = (int)(o1 - o0);
+    const float *f = fit + (shared_scan ? (size_t)b * (size_t)n : (size_t)o0);
+    const int per_lane = (n + kFitBlock - 1) / kFitBlock, run = (per_lane + kFitSub - 1) / kFitSub;
+    __syncthreads();
+    for (int q = 0; q < kFitSub; ++q) {
+      const int k0 = min(per_lane, q * run), k1 = min(per_lane, (q + 1) * run);
+      double fsum = 0.0, fcnt = 0.0;
+      for (int k = k0; k < k1; ++k) {
+        const int i = base + k * kFitBlock;
+        if (i >= n) break;
+        const float v = f[i];
+        if (v < INFINITY) { fsum += (double)v; fcnt += 1.0; }
+      }
+      fsum = wave_sum(fsum); fcnt = wave_sum(fcnt);
+      if (lane == 0) { U[(q * (kFitBlock / 64) + wave) * 2] = fsum; U[(q * (kFitBlock / 64) + wave) * 2 + 1] = fcnt; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2) {                       // units in order: groups of 16, then the groups
+      double total = 0.0;
+      for (int g = 0; g < kFitSub; ++g) {
+        double part = 0.0;
+        for (int v = 16 * g; v < 16 * g + 16; ++v) part += U[v * 2 + threadIdx.x];
+        total = g ? total + part : part;
+      }
+      U[threadIdx.x] = total;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) results[b].fitness = (n > 0 && U[1] > 0) ? U[0] / U[1] : DBL_MAX;
+  }
+}

@@ -69,7 +69,7 @@ constexpr bool kProf = false;
 // read-modify-write costs ~0.1 us and 128 waves used to queue on it every pass); it is safe because a
 // helper only counts once it has registered in `ready`, after which it does nothing but poll this word.
 struct alignas(128) ScanCtl {
-  u64 ticket;        // line 0: epoch << 32 | kind << 24 | h << 16 | uend << 8 | ubeg.  epoch 0: not open; kEpochDone: finished
+  u64 ticket;        // line 0: epoch << 32 | h << 16 | uend << 8 | ubeg.  epoch 0: not open; kEpochDone: finished
   u64 pad0_[15];
   u32 arrive;        // line 1: units published by helpers in the open epoch (one add per helper workgroup)
   u32 pad1_[31];
@@ -77,10 +77,8 @@ struct alignas(128) ScanCtl {
   int region[6];
   u32 passes;        //         passes the owner has run so far (helpers go where most were needed)
   u32 ready;         //         helpers whose window is staged; rank = order of registration
-  u32 phase;         //         1: the scan is in its fitness pass (a helper needs no window)
   u32 use_sorted;    //         1: passes read the scan from the sorted scratch copy
-  u32 owner_wg;      //         workgroup that owns the scan (its scratch slot when every match uses scan 0)
-  int pad2_[20];
+  int pad2_[22];
   u64 pose[6];       // line 3: float32 transform (c|s, tx|ty) and the four fp64 angle terms
   u64 pad3_[10];
 };
@@ -112,7 +110,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 }
 
 // pose block of the pass being computed (LDS copy)
-struct PassPose { Tf32 T; double cj, sj, ch, sh; int kind; };
+struct PassPose { Tf32 T; double cj, sj, ch, sh; };
 
 struct Lds {
   AlignState S;
@@ -128,7 +126,7 @@ struct Lds {
   unsigned long long hpose[8];     // helper: pose block of the open epoch, staged by wave 0
   unsigned long long hword;        // helper: epoch word seen by wave 0
   int hrank;                       // helper: order of registration on its scan
-  int jnext, stop;                 // units of the open segment handed out so far; close the segment
+  int jnext;                       // units of the open segment handed out so far
   unsigned diag[2];                // diagnostic: ticks of fill_window's first two phases
   int clipped;                     // owner: the scan's voxel bounding box did not fit the window
   // what a pass needs besides PP and RG, read by pass_units (a separate function: see there)
@@ -534,13 +532,12 @@ __device__ __noinline__ void pass_units(int w_in, int q0_in, int q1_in, double *
   PassPose pp;
   pp.T.c = uniform_f(pp_in.T.c); pp.T.s = uniform_f(pp_in.T.s); pp.T.tx = uniform_f(pp_in.T.tx); pp.T.ty = uniform_f(pp_in.T.ty);
   pp.cj = uniform_d(pp_in.cj); pp.sj = uniform_d(pp_in.sj); pp.ch = uniform_d(pp_in.ch); pp.sh = uniform_d(pp_in.sh);
-  pp.kind = __builtin_amdgcn_readfirstlane(pp_in.kind);
   const int lane = threadIdx.x & 63, last = n - 1;
   const int per_lane = (n + kBlock - 1) / kBlock;          // points of the longest lane
   const int run = (per_lane + kSub - 1) / kSub;
   const int kbeg = min(per_lane, q0 * run), kend = min(per_lane, q1 * run);
   const int base = w * 64 + lane;
-  if (pp.kind == 0) {
+  {
     Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
     float2 p0 = gld_f2(pts + min(base + kbeg * kBlock, last)), p1 = gld_f2(pts + min(base + (kbeg + 1) * kBlock, last));
     int q = q0, kb = min(per_lane, (q0 + 1) * run);        // end of the current run
@@ -559,36 +556,6 @@ __device__ __noinline__ void pass_units(int w_in, int q0_in, int q1_in, double *
     }
     for (; q < q1; ++q) {                                  // empty runs (short scans)
       if (lane < 12) dst[(q - q0) * dst_stride + lane] = 0.0;
-    }
-  } else {
-    for (int q = q0; q < q1; ++q) {
-      const int k0 = min(per_lane, q * run), k1 = min(per_lane, (q + 1) * run);
-      double fsum = 0.0, fcnt = 0.0;
-      // software pipeline: the offsets load of point k + 1 is in flight while the buckets of point k are read
-      // (lanes past the end of the scan search for a copy of its last point and drop the result)
-      float qx, qy;
-      {
-        const float2 pt = gld_f2(pts + min(base + k0 * kBlock, last));
-        tf_apply_t<SSE>(pp.T, pt.x, pt.y, qx, qy);
-      }
-      bool ok = (k0 < k1) && (base + k0 * kBlock < n) && finite2(qx, qy);
-      NearPrep P = nearest_prep(M, ok ? qx : 0.f, ok ? qy : 0.f);
-      for (int k = k0; k < k1; ++k) {
-        float nx, ny;
-        {
-          const float2 pt = gld_f2(pts + min(base + (k + 1) * kBlock, last));
-          tf_apply_t<SSE>(pp.T, pt.x, pt.y, nx, ny);
-        }
-        const bool nok = (k + 1 < k1) && (base + (k + 1) * kBlock < n) && finite2(nx, ny);
-        const NearPrep PN = nearest_prep(M, nok ? nx : 0.f, nok ? ny : 0.f);
-        if (ok) {
-          const float best = nearest_finish(M, qx, qy, P);
-          if (best < INFINITY) { fsum += (double)best; fcnt += 1.0; }
-        }
-        qx = nx; qy = ny; ok = nok; P = PN;
-      }
-      fsum = wave_sum(fsum); fcnt = wave_sum(fcnt);
-      if (lane == 0) { dst[(q - q0) * dst_stride] = fsum; dst[(q - q0) * dst_stride + 1] = fcnt; }
     }
   }
 }
@@ -653,8 +620,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       const u64 q0 = kProf ? wall_clock64() : 0;
       compute_region<SSE>(M, L.S.T, scan, n, L);
       const u64 q1 = kProf ? wall_clock64() : 0;
-      // scratch copy: at the scan's own offsets, or (every match uses scan 0) one slot per workgroup
-      float2 *sp = sorted ? (shared_scan ? sorted + (size_t)blockIdx.x * (size_t)n : sorted + o0) : nullptr;
+      // scratch copy: at the scan's own offsets, or (every match uses scan 0) one slot per match
+      float2 *sp = sorted ? (shared_scan ? sorted + (size_t)b * (size_t)n : sorted + o0) : nullptr;
       if (sort_points<SSE>(M, L.S.T, scan, n, L, pool, sp)) pts = sp;
       const u64 q2 = kProf ? wall_clock64() : 0;
       if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
@@ -670,7 +637,6 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
           C->region[0] = r.x0; C->region[1] = r.y0; C->region[2] = r.rw; C->region[3] = r.rh;
           C->region[4] = r.cap; C->region[5] = r.nspill;
           C->use_sorted = (pts != scan) ? 1u : 0u;
-          C->owner_wg = blockIdx.x;
         }
         drain_vmem();
         __syncthreads();
@@ -693,11 +659,9 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     u64 ts1 = 0, ts2 = 0, ts3 = 0, a_pro = 0, a_own = 0, a_wait = 0, a_comb = 0, a_adv = 0, a_n = 0;   // shared derivative passes (diagnostic)
     const u64 t_scan0 = kProf ? wall_clock64() - t_start : 0;
     unsigned n_shared = 0, n_helped = 0;
-    bool fitness_done = false;
-    // ---- passes: derivative passes until the optimiser stops, then one fitness pass ----
-    while (n > 0 && !fitness_done) {
+    // ---- derivative passes until the optimiser stops (the fitness score is a kernel of its own: ndt_fitness.hip.h) ----
+    while (n > 0 && L.S.phase != PH_DONE) {
       if (kProf && prof) tt0 = wall_clock64();
-      const bool fit_pass = (L.S.phase == PH_DONE);
       // A pass is run as one or more SEGMENTS of consecutive units.  A derivative pass is one segment:
       // solo (one walk per wave) or split over the registered helpers.  The fitness pass runs once, can
       // be long (a poor match walks many rings per point) and usually starts when no helper is free:
@@ -709,14 +673,13 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         if (threadIdx.x == 0) {
           if (seg == 0) {
             L.PP.T = L.S.T; L.PP.cj = L.S.cj; L.PP.sj = L.S.sj; L.PP.ch = L.S.ch; L.PP.sh = L.S.sh;
-            L.PP.kind = fit_pass ? 1 : 0;
-            if (allow_helpers) { st32(&C->passes, (u32)L.S.evals); if (fit_pass) st32(&C->phase, 1u); }
+            if (allow_helpers) st32(&C->passes, (u32)L.S.evals);
           } else if (allow_helpers) {
             L.sflag[1] = (int)ld32(&C->ready);
           }
           const int h = allow_helpers ? min(L.sflag[1], kMaxHelpers) : 0;
           L.sflag[0] = h;
-          L.jnext = 0; L.stop = 0;
+          L.jnext = 0;
           if (h > 0) {                          // open an epoch: pose block, then the epoch word
             const PassPose pp = L.PP;
             if (!pose_out) {
@@ -728,37 +691,25 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
             }
             st32(&C->arrive, 0u);
             drain_vmem();
-            st64(&C->ticket, ((u64)(epoch + 1) << 32) | ((u64)pp.kind << 24) | ((u64)h << 16) | ((u64)kUnits << 8) | (u64)ubeg);
+            st64(&C->ticket, ((u64)(epoch + 1) << 32) | ((u64)h << 16) | ((u64)kUnits << 8) | (u64)ubeg);
           }
         }
         __syncthreads();
         if (kProf && prof) ts1 = wall_clock64();
         const int nhelp = L.sflag[0];
         int uend = kUnits;
-        if (nhelp <= 0 && !fit_pass) {
-          // solo derivative pass: wave w computes its own units (w, 0..kSub-1) in one walk
+        if (nhelp <= 0) {
+          // solo pass: wave w computes its own units (w, 0..kSub-1) in one walk
           pass_units<SSE, INCL>(wave, 0, kSub, L.wpart + wave * 12, kWaves * 12);
         } else {
           // this workgroup's units ubeg + j*(nhelp+1), j = 0, 1, ... handed to its waves from an LDS counter
-          const bool watch = fit_pass && nhelp == 0 && allow_helpers;
           for (int it = 0; it <= kUnits; ++it) {             // counted (tools/repro/ticket2.hip)
-            if (watch && L.stop) break;
             int j = 0;
             if (lane == 0) j = atomicAdd(&L.jnext, 1);
             j = __builtin_amdgcn_readfirstlane(j);
             const int u = ubeg + j * (nhelp + 1);
             if (u >= kUnits) break;
             pass_units<SSE, INCL>(u % kWaves, u / kWaves, u / kWaves + 1, L.wpart + u * 12, 0);
-            if (watch && wave == kWaves - 1 && lane == 0) {
-              // one wave looks for a registered helper between its units.  (Raising the scan's priority
-              // when this pass runs long was tried: it draws helpers away from the scans that still have
-              // tens of passes to go and cost 5 % of the batch rate.)
-              if (ld32(&C->ready) > 0u) L.stop = 1;
-            }
-          }
-          if (watch) {                                       // units [ubeg, ubeg + claimed) are done
-            __syncthreads();
-            uend = min(kUnits, ubeg + L.jnext);
           }
         }
         if (nhelp > 0) {
@@ -809,18 +760,17 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (kProf && prof) { tt1 = wall_clock64(); }
-        if (!fit_pass && lane == 0) advance(L.S, P, M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
+        if (lane == 0) advance(L.S, P, M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
       }
       // meanwhile another wave fetches the number of registered helpers for the next pass
-      if (!fit_pass && threadIdx.x == 64 && allow_helpers) L.sflag[1] = (int)rd32_fresh(&C->ready);
-      if (fit_pass) fitness_done = true;
+      if (threadIdx.x == 64 && allow_helpers) L.sflag[1] = (int)rd32_fresh(&C->ready);
       __syncthreads();
       if (kProf && prof) {
         const u64 te = wall_clock64();
         if (threadIdx.x >= 64) tt1 = te;          // (only wave 0 stamps the end of the summation)
-        t_eval += tt1 - tt0; if (fit_pass) t_fit = tt1 - tt0;
+        t_eval += tt1 - tt0;
         t_adv += te - tt1;
-        if (pass_h > 0 && !fit_pass) { a_pro += ts1 - tt0; a_own += ts2 - ts1; a_wait += ts3 - ts2; a_comb += tt1 - ts3; a_adv += te - tt1; a_n += 1; }
+        if (pass_h > 0) { a_pro += ts1 - tt0; a_own += ts2 - ts1; a_wait += ts3 - ts2; a_comb += tt1 - ts3; a_adv += te - tt1; a_n += 1; }
       }
     }
     // ---- result record; close the scan ----
@@ -830,7 +780,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       ndt_result R_;
       R_.pose[0] = (double)T.tx; R_.pose[1] = (double)T.ty; R_.pose[2] = yaw_from_T(T.c, T.s);
       R_.T00 = T.c; R_.T10 = T.s; R_.T03 = T.tx; R_.T13 = T.ty;
-      R_.fitness = (fitness_done && L.tot[1] > 0) ? L.tot[0] / L.tot[1] : DBL_MAX;
+      R_.fitness = DBL_MAX;                 // written by fitness_reduce_kernel, queued behind this kernel
       R_.score = S.score;
       R_.trans_prob = n > 0 ? S.score / (double)n : 0.0;
       R_.H[0] = S.H[0]; R_.H[1] = S.H[1]; R_.H[2] = S.H[2];
@@ -926,7 +876,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     const u64 o0 = shared_scan ? offsets[0] : offsets[vb];
     const u64 o1 = shared_scan ? offsets[1] : offsets[vb + 1];
     const int n = (int)(o1 - o0);
-    if (threadIdx.x == 0) { L.sflag[1] = (int)C->use_sorted; L.sflag[0] = (int)C->owner_wg; }
+    if (threadIdx.x == 0) L.sflag[1] = (int)C->use_sorted;
     if (threadIdx.x == 0) {
       Region r; r.x0 = C->region[0]; r.y0 = C->region[1]; r.rw = C->region[2]; r.rh = C->region[3];
       r.cap = C->region[4]; r.nspill = C->region[5];
@@ -937,12 +887,10 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       const unsigned *gw = wantmap + (size_t)vb * (kRegionCells / 32);
       for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) wmap[i] = gw[i];
     }
-    if (threadIdx.x == 0) L.sflag[2] = (int)ld32(&C->phase);
     __syncthreads();
-    const int owner_wg = L.sflag[0];
-    const float2 *pts = L.sflag[1] ? (shared_scan ? sorted + (size_t)owner_wg * (size_t)n : sorted + o0)
+    const float2 *pts = L.sflag[1] ? (shared_scan ? sorted + (size_t)vb * (size_t)n : sorted + o0)
                                    : (reinterpret_cast<const float2 *>(scans) + o0);
-    if (L.sflag[2] == 0) fill_window(M, L, pool);          // a scan in its fitness pass needs no window
+    fill_window(M, L, pool);
     if (threadIdx.x == 0) { L.pts = pts; L.npts = n; }
     if (kProf && prof && threadIdx.x == 0 && prof[8 * vb + 5] == 0) prof[8 * vb + 5] = wall_clock64() - t_start;
     u64 *vtot = utot + (size_t)vb * kUnits * 12;
@@ -972,12 +920,10 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
           if (lane < 6) pw = ld64(&C->pose[lane]);
           const u64 w0 = __shfl(pw, 0), w1 = __shfl(pw, 1);
           if (lane == 0) {
-            PassPose q;
+            struct { Tf32 T; } q;
             q.T.c = __uint_as_float((u32)w0); q.T.s = __uint_as_float((u32)(w0 >> 32));
             q.T.tx = __uint_as_float((u32)w1); q.T.ty = __uint_as_float((u32)(w1 >> 32));
-            q.cj = 0; q.sj = 0; q.ch = 0; q.sh = 0;
-            q.kind = (int)((word >> 24) & 0xFFu);
-            L.PP.T = q.T; L.PP.kind = q.kind;
+            L.PP.T = q.T;
           }
           if (lane >= 2 && lane < 6) (&L.PP.cj)[lane - 2] = __longlong_as_double((long long)pw);   // cj, sj, ch, sh
         }

@@ -70,7 +70,8 @@ struct ndt_ctx {
   void *d_tmp = nullptr; size_t d_tmp_cap = 0;
   void *d_trace = nullptr; size_t d_trace_cap = 0;
   void *d_rows = nullptr; size_t d_rows_cap = 0;
-  void *d_sorted = nullptr; size_t d_sorted_cap = 0;   // per-lane ordered copy of the scans
+  void *d_sorted = nullptr; size_t d_sorted_cap = 0;   // cell-ordered copy of the scans
+  void *d_fit = nullptr; size_t d_fit_cap = 0;         // squared distance to the nearest map point, per scan point
   void *d_ws = nullptr; size_t d_ws_cap = 0;           // WsHeader + ScanCtl[B] + chunk totals
   void *d_pf = nullptr; size_t d_pf_cap = 0;           // pre-filter: filtered points at the raw offsets + counts
   void *d_rn = nullptr; size_t d_rn_cap = 0;           // neighbour removal: block offsets + keep flags
@@ -179,8 +180,8 @@ int grid_for(size_t n, int block, int cap = 2048) {
 }
 
 int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *scans,
-                 const unsigned long long *offsets, int B, int shared_scan, const double *inits, ndt_result *out,
-                 double *trace, int trace_cap, int *trace_rows, float2 *sorted, unsigned long long *prof) {
+                 const unsigned long long *offsets, int B, int shared_scan, size_t total_points, const double *inits,
+                 ndt_result *out, double *trace, int trace_cap, int *trace_rows, unsigned long long *prof) {
   const bool sse = map->prm.transform_sse != 0, incl = map->prm.radius_inclusive != 0;
   const MapView &V = map->view;
   const OptParams O = opt_of(map->prm);
@@ -189,6 +190,13 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   const size_t ws_bytes = zero_bytes + (size_t)B * kUnits * 12 * sizeof(double) + (size_t)B * (kRegionCells / 8);
   int rc = ensure(ctx, &ctx->d_ws, &ctx->d_ws_cap, ws_bytes);
   if (rc) return rc;
+  // ordered copy of every scan (what the passes and the fitness kernel read) and one float per point for the
+  // fitness score; when every match uses scan 0 each match has its own slot of the scan's size
+  const size_t slots = (shared_scan ? (size_t)B : (size_t)1) * total_points;
+  if ((rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, slots * sizeof(float2) + 16))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_fit, &ctx->d_fit_cap, slots * sizeof(float) + 16))) return rc;
+  float2 *sorted = (float2 *)ctx->d_sorted;
+  float *fit = (float *)ctx->d_fit;
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ws, 0, zero_bytes, st));
   unsigned char *ws = (unsigned char *)ctx->d_ws;
   const int helpers = ctx->helpers;
@@ -203,6 +211,15 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   else if (incl)   NDT_LAUNCH(false, true);
   else             NDT_LAUNCH(false, false);
 #undef NDT_LAUNCH
+  // a7: fitness scores, behind the matches on the same stream
+  {
+    const size_t avg = shared_scan ? total_points : (total_points + (size_t)B - 1) / (size_t)B;
+    const unsigned gx = (unsigned)std::min<size_t>(64, std::max<size_t>(1, (avg + 255) / 256));
+    const dim3 grid(gx, (unsigned)std::min(B, 65535));
+    if (sse) fitness_points_kernel<true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit);
+    else     fitness_points_kernel<false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit);
+    fitness_reduce_kernel<<<std::min(B, 4 * ctx->num_cus), kFitBlock, 0, st>>>(offsets, B, shared_scan, fit, out);
+  }
   HIP_TRY(ctx, hipGetLastError());
   return NDT_OK;
 }
@@ -317,7 +334,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->ev_mm) e = hipEventDestroy(c->ev_mm);
   if (c->ev_scratch) e = hipEventDestroy(c->ev_scratch);
   if (c->h_mm) e = hipHostFree(c->h_mm);
-  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
+  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_fit, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
   delete c;
@@ -582,14 +599,9 @@ int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, co
   if (st != map->ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(st, map->ctx->evm1, 0));
   int rc;
   if ((rc = scratch_begin(ctx, st))) return rc;
-  float2 *sorted = nullptr;
-  if (total_points > 0) {                      // shared scan: one slot of the scan's size per workgroup
-    rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (shared_scan ? (size_t)ctx->num_cus : (size_t)1) * total_points * 8);
-    if (rc) return rc;
-    sorted = (float2 *)ctx->d_sorted;
-  }
-  if ((rc = launch_align(ctx, map, st, scans, (const unsigned long long *)offsets, B, shared_scan, inits, out,
-                         nullptr, 0, nullptr, sorted, nullptr)))
+  if (total_points == 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: total_points = 0");
+  if ((rc = launch_align(ctx, map, st, scans, (const unsigned long long *)offsets, B, shared_scan, total_points, inits,
+                         out, nullptr, 0, nullptr, nullptr)))
     return rc;
   return scratch_end(ctx, st);
 }
@@ -677,11 +689,9 @@ int align_host(ndt_ctx *ctx, const ndt_map *map, const float *scans, size_t stri
   if (want_prof) { HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 128)); HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, (size_t)B * 128, st)); }
 #endif
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
-  if ((rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, (shared_scan ? (size_t)ctx->num_cus : (size_t)1) * ntot * 8))) return rc;
-  float2 *sorted = (float2 *)ctx->d_sorted;
   if ((rc = launch_align(ctx, map, st, (const float *)ctx->d_scan, (const unsigned long long *)ctx->d_off, B,
-                         shared_scan, (const double *)ctx->d_init, (ndt_result *)ctx->d_res, d_trace, trace_cap,
-                         d_rows, sorted, d_prof)))
+                         shared_scan, ntot, (const double *)ctx->d_init, (ndt_result *)ctx->d_res, d_trace, trace_cap,
+                         d_rows, d_prof)))
     return rc;
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
 #ifdef NDT_DIAG
