@@ -280,6 +280,11 @@ int ndt_make_map_dev(ndt_ctx *ctx, const float *scans_xy_dev, size_t stride_byte
                      int n_scans, int first_submap, int newest, int remove_moving, double resol,
                      double thre_neighbor, float *out_xy_dev, uint64_t *n_out_dev, void *stream);
 
+/* Durations of the kernels of one of the context's last 64 match launches (`back` = 0: the most recent one):
+ * the match kernel (rows a3-a6, a8, a9) and the fitness kernels behind it (row a7), from HIP events recorded around
+ * them on the launch's stream.  Blocks until that launch has finished. */
+int ndt_kernel_timing(ndt_ctx *ctx, int back, float *match_ms, float *fitness_ms);
+
 /* Timing hooks used by bench.py (HIP events on the context's stream; milliseconds of the most
  * recent call of each kind, measured around the kernel launches only). */
 int ndt_last_timing(const ndt_ctx *ctx, float *map_build_ms, float *align_ms);

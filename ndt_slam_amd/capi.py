@@ -57,7 +57,7 @@ EXPORTS = [
     "ndt_ctx_set_stream", "ndt_ctx_set_option",
     "ndt_map_build", "ndt_map_build_dev", "ndt_map_destroy", "ndt_map_info_get", "ndt_map_export",
     "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_trace", "ndt_eval_at",
-    "ndt_fitness_at", "ndt_last_timing", "ndt_prefilter", "ndt_prefilter_batch_dev",
+    "ndt_fitness_at", "ndt_last_timing", "ndt_kernel_timing", "ndt_prefilter", "ndt_prefilter_batch_dev",
     "ndt_fuse_default_params", "ndt_predict_batch_dev", "ndt_fuse_batch_dev",
     "ndt_remove_neighbors", "ndt_remove_neighbors_dev",
     "ndt_difference_extraction", "ndt_difference_extraction_dev", "ndt_make_map", "ndt_make_map_dev",
@@ -96,6 +96,7 @@ def lib():
     L.ndt_eval_at.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp, vp, vp]
     L.ndt_fitness_at.argtypes = [vp, vp, vp, sz, sz, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     L.ndt_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ndt_kernel_timing.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ndt_prefilter.argtypes = [vp, vp, sz, sz, C.c_float, vp, C.POINTER(sz)]
     L.ndt_prefilter_batch_dev.argtypes = [vp, vp, sz, vp, i, sz, C.c_float, vp, vp, vp]
     L.ndt_fuse_default_params.argtypes = [C.POINTER(FuseParams)]
@@ -247,6 +248,12 @@ class Context:
     def last_timing(self):
         a, b = C.c_float(), C.c_float()
         lib().ndt_last_timing(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def kernel_timing(self, back=0):
+        """(match kernel ms, fitness kernels ms) of one of this context's last 64 launches; blocks until it is done."""
+        a, b = C.c_float(), C.c_float()
+        self.check(lib().ndt_kernel_timing(self.h, back, C.byref(a), C.byref(b)), "ndt_kernel_timing")
         return a.value, b.value
 
     def close(self):

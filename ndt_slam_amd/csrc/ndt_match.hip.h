@@ -59,6 +59,8 @@ constexpr bool kProf = true;
 #else
 constexpr bool kProf = false;
 #endif
+// diagnostic builds: thread 0 of the owner stamps the setup phases of a scan (ticks since the scan was taken)
+#define NDT_STAMP(st_, t0_, k_) do { if (kProf && (st_) && threadIdx.x == 0) (st_)[k_] = wall_clock64() - (t0_); } while (0)
 
 // Per-scan control block: four 128-byte lines, so that the words touched by different parties
 // (epoch polls / arrivals / attach + ready counts / pose reads) never share a line.
@@ -209,7 +211,7 @@ __device__ __forceinline__ void compute_region(const MapView &M, const Tf32 &T0,
 // LDS record (centroid -inf).  Sets L.RG.nspill = occupied voxels left without a record.
 // Cells are walked 1024 at a time with consecutive lanes on consecutive cells (coalesced centroid
 // and record reads); the row-major numbering comes from wave ballots kept in LDS.
-__device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool) {
+__device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool, u64 *stamps = nullptr, u64 t0s = 0) {
   const Region r = L.RG;
   const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
   unsigned short *slot = reinterpret_cast<unsigned short *>(pool);
@@ -221,30 +223,35 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
   u64 *keepw = reinterpret_cast<u64 *>(L.wpart) + 256;        // [rounds][kWaves] ballots (wmap uses the first 2 KiB)
   u64 *occw = keepw + 256;
   int *base = reinterpret_cast<int *>(L.wtmp);                // [256] exclusive prefix of the kept counts
-  // which window cells are in the map's search set: one bit each from the map's occupancy words,
-  // all rounds' loads in flight together, then one ballot per round
-  unsigned ow[kRegionCells / kBlock];
-  const int rw1 = max(r.rw, 1), step_y = kBlock / rw1, step_x = kBlock - step_y * rw1;   // one round further on
-  int ly = (int)threadIdx.x / rw1, lx = (int)threadIdx.x - ly * rw1;
-#pragma unroll
-  for (int j = 0; j < kRegionCells / kBlock; ++j) {
-    const int c = j * kBlock + threadIdx.x;
-    ow[j] = 0u;
-    if (j < rounds && c < ncell) {
-      const int mx = r.x0 + lx, my = r.y0 + ly;
-      if (mx >= 0 && mx < M.div_x && my >= 0 && my < M.div_y) {
-        const size_t g = (size_t)my * M.div_x + mx;
-        ow[j] = (M.occ[g >> 5] >> (g & 31)) & 1u;
+  // which window cells are in the map's search set: the window's occupancy bitmap in cell order (64 cells per
+  // word = what a wave ballot over 64 consecutive cells would give), each 32-bit half assembled by one thread from
+  // the map's occupancy words -- a run of window cells in one row is a run of bits of the map's bitmap.
+  // (One load per CELL, 16 per thread, took 12 us here.)
+  {
+    constexpr int kWords32 = kRegionCells / 32;
+    unsigned *occ32 = reinterpret_cast<unsigned *>(occw);
+    const int rw1 = max(r.rw, 1);
+    for (int i = threadIdx.x; i < kWords32; i += kBlock) {
+      unsigned word = 0u;
+      int c = 32 * i, filled = 0;
+      int ly = c / rw1, lx = c - ly * rw1;
+      for (int piece = 0; piece < 34 && filled < 32 && c < ncell; ++piece) {
+        const int len = min(32 - filled, r.rw - lx);             // cells of row ly from lx on
+        const int my = r.y0 + ly, a = r.x0 + lx;
+        const int lo = max(a, 0), hi = min(a + len, M.div_x);
+        if (my >= 0 && my < M.div_y && lo < hi) {
+          const size_t g = (size_t)my * M.div_x + lo;
+          const unsigned w0 = M.occ[g >> 5], w1 = M.occ[(g >> 5) + 1];    // (the bitmap has two spare words)
+          const u64 two = ((u64)w1 << 32) | w0;
+          const unsigned bits = (unsigned)(two >> (g & 31)) & (hi - lo >= 32 ? 0xFFFFFFFFu : ((1u << (hi - lo)) - 1u));
+          word |= bits << (filled + (lo - a));
+        }
+        filled += len; c += len; lx = 0; ++ly;
       }
+      occ32[i] = word;
     }
-    lx += step_x; ly += step_y;
-    if (lx >= rw1) { lx -= rw1; ++ly; }
   }
-#pragma unroll
-  for (int j = 0; j < kRegionCells / kBlock; ++j) {
-    const u64 ob = __ballot(ow[j] != 0u);
-    if (lane == 0) occw[j * kWaves + wave] = ob;           // rounds past the window: zero
-  }
+  NDT_STAMP(stamps, t0s, 7);
   // marked cells dilated by two cells in x and y, on whole words: a voxel gets an LDS record when it
   // is in the search set and within two cells of a cell a scan point fell in.  (Rows are not word
   // aligned, so a mark in the first or last two columns of the window also reaches the end of the
@@ -275,6 +282,7 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
   if (threadIdx.x < kWords) dx[threadIdx.x] = kword;        // = keepw, two words per ballot word
   __syncthreads();
   if (kProf && threadIdx.x == 0) L.diag[0] = (unsigned)(wall_clock64() - t_fill0);
+  NDT_STAMP(stamps, t0s, 8);
   // exclusive prefix of the kept counts over the rounds * kWaves ballot words (cell order)
   const int nword = rounds * kWaves;                           // <= 256
   if (threadIdx.x < 256) {
@@ -306,38 +314,64 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
     if (kProf) L.diag[1] = (unsigned)(wall_clock64() - t_fill0);
   }
   __syncthreads();
-  for (int j0 = 0; j0 < rounds; j0 += 4) {                   // four rounds' record loads in flight together
-    int nx[4]; float2 cc[4]; double2 ra[4], rb[4]; double rc[4]; unsigned sl[4];
+  NDT_STAMP(stamps, t0s, 9);
+  // slot table: every cell of the window (no global memory involved)
+  for (int j = 0; j < rounds; ++j) {
+    const int c = j * kBlock + threadIdx.x;
+    if (c >= ncell) break;
+    const u64 kb = keepw[j * kWaves + wave], ob = occw[j * kWaves + wave];
+    unsigned sl = (unsigned)r.cap;
+    if ((ob >> lane) & 1ull) {
+      sl = (unsigned)r.cap + 1u;
+      if ((kb >> lane) & 1ull) {
+        const int next = base[j * kWaves + wave] + __builtin_popcountll(kb & ((1ull << lane) - 1ull));
+        if (next < r.cap) sl = (unsigned)next;
+      }
+    }
+    slot[c] = (unsigned short)sl;
+  }
+  // records: thread t fetches records t, t + 1024, ... (at most kRecPer) -- the cell of record number k is found
+  // from the prefix sums (which ballot word, which set bit), so that ALL of a thread's loads are in flight together
+  // (walking the cells round by round, four rounds of loads at a time, took 14 us: four dependent latencies)
+  {
+    constexpr int kRecPer = 4;
+    const int kept = min(L.swave[0] + L.swave[1] + L.swave[2] + L.swave[3], r.cap);
+    static_assert(kPoolBytes / (int)sizeof(CellEntry) <= kRecPer * kBlock, "a thread fetches at most kRecPer records");
+    int nx[kRecPer]; float2 cc[kRecPer]; double2 ra[kRecPer], rb[kRecPer]; double rc[kRecPer];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = j0 + u, c = j * kBlock + threadIdx.x;
-      nx[u] = -1; sl[u] = (unsigned)r.cap;
-      if (j < rounds && c < ncell) {
-        const u64 kb = keepw[j * kWaves + wave], ob = occw[j * kWaves + wave];
-        if ((ob >> lane) & 1ull) {
-          sl[u] = (unsigned)r.cap + 1u;
-          if ((kb >> lane) & 1ull) {
-            const int next = base[j * kWaves + wave] + __builtin_popcountll(kb & ((1ull << lane) - 1ull));
-            if (next < r.cap) {
-              const int ly = c / r.rw, lx = c - ly * r.rw;
-              const size_t pg = (size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2);
-              const double *rec = M.rec + pg * 8;
-              cc[u] = M.cent[pg];
-              ra[u] = *reinterpret_cast<const double2 *>(rec); rb[u] = *reinterpret_cast<const double2 *>(rec + 2); rc[u] = rec[4];
-              nx[u] = next; sl[u] = (unsigned)next;
-            }
-          }
+    for (int u = 0; u < kRecPer; ++u) {
+      const int k = (int)threadIdx.x + u * kBlock;
+      nx[u] = -1;
+      if (k < kept) {
+        int lo = 0, hi = nword - 1;                          // last ballot word whose exclusive prefix is <= k
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int mid = (lo + hi + 1) >> 1;
+          if (base[mid] <= k) lo = mid; else hi = mid - 1;
         }
+        u64 v = keepw[lo];
+        int nth = k - base[lo], pos = 0;                     // the nth set bit of v (0-based)
+#pragma unroll
+        for (int sh = 32; sh >= 1; sh >>= 1) {
+          const u64 lowmask = (1ull << sh) - 1ull;
+          const int cnt = __builtin_popcountll(v & lowmask);
+          if (nth >= cnt) { nth -= cnt; v >>= sh; pos += sh; } else { v &= lowmask; }
+        }
+        const int c = lo * 64 + pos;
+        const int ly = c / r.rw, lx = c - ly * r.rw;
+        const size_t pg = (size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2);
+        const double *rec = M.rec + pg * 8;
+        cc[u] = M.cent[pg];
+        ra[u] = *reinterpret_cast<const double2 *>(rec); rb[u] = *reinterpret_cast<const double2 *>(rec + 2); rc[u] = rec[4];
+        nx[u] = k;
       }
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = j0 + u, c = j * kBlock + threadIdx.x;
+    for (int u = 0; u < kRecPer; ++u) {
       if (nx[u] >= 0) {
         CellEntry E; E.cent = cc[u]; E.mx = ra[u].x; E.my = ra[u].y; E.i00 = rb[u].x; E.i01 = rb[u].y; E.i11 = rc[u];
         ent[nx[u]] = E;
       }
-      if (j < rounds && c < ncell) slot[c] = (unsigned short)sl[u];
     }
   }
   __syncthreads();
@@ -355,7 +389,8 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
 constexpr int kSortMax = 20000;             // LDS room for one word per point; point numbers < 2^15
 template <bool SSE>
 __device__ __forceinline__ bool sort_points(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
-                                            int n, Lds &L, uint4 *pool, float2 *__restrict__ sp) {
+                                            int n, Lds &L, uint4 *pool, float2 *__restrict__ sp,
+                                            u64 *stamps = nullptr, u64 t0s = 0) {
   const Region r = L.RG;
   const int ncell = r.rw * r.rh;
   unsigned *wmap = reinterpret_cast<unsigned *>(L.wpart);
@@ -382,12 +417,15 @@ __device__ __forceinline__ bool sort_points(const MapView &M, const Tf32 &T0, co
     for (int u = 0; u < 4; ++u) if (i0 + u * kBlock < n) atomicAdd(&hist[key_of(pt[u])], 1u);
   }
   __syncthreads();
-  // marked-cell bitmap
-  for (int w = threadIdx.x; w < (ncell + 31) / 32; w += kBlock) {
-    unsigned bits = 0;
-    const int c0 = w * 32, c1 = min(c0 + 32, ncell);
-    for (int c = c0; c < c1; ++c) bits |= (hist[c] != 0u ? 1u : 0u) << (c - c0);
-    wmap[w] = bits;
+  NDT_STAMP(stamps, t0s, 2);
+  // marked-cell bitmap: 64 consecutive cells per wave ballot (bank-conflict-free reads)
+  {
+    u64 *wmap64 = reinterpret_cast<u64 *>(wmap);
+    for (int c0 = (int)(threadIdx.x & ~63u); c0 < ncell; c0 += kBlock) {
+      const int c = c0 + (int)(threadIdx.x & 63u);
+      const u64 bits = __ballot(c < ncell && hist[c] != 0u);
+      if ((threadIdx.x & 63u) == 0u) wmap64[c0 >> 6] = bits;
+    }
   }
   const bool do_sort = sp != nullptr && n <= kSortMax;
   if (!do_sort) { __syncthreads(); return false; }
@@ -411,6 +449,7 @@ __device__ __forceinline__ bool sort_points(const MapView &M, const Tf32 &T0, co
     for (int c = c0; c < c1; ++c) { const unsigned t = hist[c]; hist[c] = run; run += t; }
   }
   __syncthreads();
+  NDT_STAMP(stamps, t0s, 3);
   // scatter (cell, point number) packed in one word; afterwards hist[c] = end of cell c
   for (int i0 = threadIdx.x; i0 < n; i0 += 4 * kBlock) {
     float2 pt[4];
@@ -424,6 +463,7 @@ __device__ __forceinline__ bool sort_points(const MapView &M, const Tf32 &T0, co
     }
   }
   __syncthreads();
+  NDT_STAMP(stamps, t0s, 4);
   // input order inside a cell (the atomics above arrive in any order): every entry finds its rank among
   // the entries of its cell -- neighbouring lanes read the same short segment -- and its point goes
   // straight to that place of the scratch copy
@@ -616,13 +656,18 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     }
     __syncthreads();
     const float2 *pts = scan;
+    u64 *const stamps = (kProf && prof) ? prof + 16 * (size_t)B + 16 * (size_t)b : nullptr;
+    const u64 t0s = kProf ? wall_clock64() : 0;
     if (n > 0) {
       const u64 q0 = kProf ? wall_clock64() : 0;
-      compute_region<SSE>(M, L.S.T, scan, n, L);
-      const u64 q1 = kProf ? wall_clock64() : 0;
+      NDT_STAMP(stamps, t0s, 0);
       // scratch copy: at the scan's own offsets, or (every match uses scan 0) one slot per match
       float2 *sp = sorted ? (shared_scan ? sorted + (size_t)b * (size_t)n : sorted + o0) : nullptr;
-      if (sort_points<SSE>(M, L.S.T, scan, n, L, pool, sp)) pts = sp;
+      compute_region<SSE>(M, L.S.T, scan, n, L);
+      const u64 q1 = kProf ? wall_clock64() : 0;
+      NDT_STAMP(stamps, t0s, 1);
+      if (sort_points<SSE>(M, L.S.T, scan, n, L, pool, sp, stamps, t0s)) pts = sp;
+      NDT_STAMP(stamps, t0s, 5);
       const u64 q2 = kProf ? wall_clock64() : 0;
       if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
         const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
@@ -646,7 +691,9 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
           st64(&C->ticket, (u64)1 << 32);                     // epoch 1: open for joining, nothing to compute (h = 0)
         }
       }
-      fill_window(M, L, pool);
+      NDT_STAMP(stamps, t0s, 6);
+      fill_window(M, L, pool, stamps, t0s);
+      NDT_STAMP(stamps, t0s, 10);
       const u64 q3 = kProf ? wall_clock64() : 0;
       if (kProf && prof && threadIdx.x == 0) {
         prof[8 * (size_t)B + 8 * (size_t)b + 6] = ((q1 - q0) << 32) | ((q2 - q1) & 0xFFFFFFFFull);

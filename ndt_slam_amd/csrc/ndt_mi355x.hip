@@ -84,6 +84,10 @@ struct ndt_ctx {
   // The grow-only scratch above belongs to the context, not to a stream: a call on another stream than the
   // previous one first waits for the previous user (ev_scratch).
   hipEvent_t ev_scratch = nullptr; hipStream_t scratch_stream = nullptr; bool scratch_used = false;
+  // ring of timing events around the kernels of the last kTimeRing match launches: start, matches done, fitness done
+  static constexpr int kTimeRing = 64;
+  hipEvent_t ev_ring[3 * kTimeRing] = {};
+  unsigned long long launches = 0;
 };
 
 struct ndt_map {
@@ -203,6 +207,8 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   // one workgroup per CU (the LDS window allows no more); idle workgroups help unfinished scans
   const int ncu = ctx->workgroups > 0 ? ctx->workgroups : ctx->num_cus;
   const int grid = helpers ? ncu : (B < ncu ? B : ncu);
+  hipEvent_t *evr = ctx->ev_ring + 3 * (ctx->launches % ndt_ctx::kTimeRing);
+  HIP_TRY(ctx, hipEventRecord(evr[0], st));
 #define NDT_LAUNCH(S_, I_)                                                                           \
   ndt_align_kernel<S_, I_><<<grid, kBlock, 0, st>>>(V, O, scans, offsets, B, shared_scan, inits, out, trace, \
                                                     trace_cap, trace_rows, sorted, ws, helpers, prof)
@@ -211,6 +217,7 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   else if (incl)   NDT_LAUNCH(false, true);
   else             NDT_LAUNCH(false, false);
 #undef NDT_LAUNCH
+  HIP_TRY(ctx, hipEventRecord(evr[1], st));
   // a7: fitness scores, behind the matches on the same stream
   {
     const size_t avg = shared_scan ? total_points : (total_points + (size_t)B - 1) / (size_t)B;
@@ -220,6 +227,8 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
     else     fitness_points_kernel<false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit);
     fitness_reduce_kernel<<<std::min(B, 4 * ctx->num_cus), kFitBlock, 0, st>>>(offsets, B, shared_scan, fit, out);
   }
+  HIP_TRY(ctx, hipEventRecord(evr[2], st));
+  ctx->launches++;
   HIP_TRY(ctx, hipGetLastError());
   return NDT_OK;
 }
@@ -282,6 +291,7 @@ static int ctx_init(ndt_ctx *c, int device) {
   HIP_TRY(c, hipEventCreateWithFlags(&c->evb, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming));
+  for (hipEvent_t &e : c->ev_ring) HIP_TRY(c, hipEventCreate(&e));
   HIP_TRY(c, hipHostMalloc((void **)&c->h_bounds, 64, hipHostMallocDefault));
   { int rc = upload_exp_table(c); if (rc) return rc; }
   hipDeviceProp_t prop;
@@ -333,6 +343,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->h_bounds) e = hipHostFree(c->h_bounds);
   if (c->ev_mm) e = hipEventDestroy(c->ev_mm);
   if (c->ev_scratch) e = hipEventDestroy(c->ev_scratch);
+  for (hipEvent_t r : c->ev_ring) if (r) e = hipEventDestroy(r);
   if (c->h_mm) e = hipHostFree(c->h_mm);
   void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_fit, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
   for (void *b : bufs) if (b) e = hipFree(b);
@@ -361,6 +372,19 @@ int ndt_last_timing(const ndt_ctx *cc, float *map_ms, float *align_ms) {
   }
   if (map_ms) *map_ms = c->map_ms;
   if (align_ms) *align_ms = c->align_ms;
+  return NDT_OK;
+}
+
+int ndt_kernel_timing(ndt_ctx *c, int back, float *match_ms, float *fitness_ms) {
+  if (!c || back < 0 || back >= ndt_ctx::kTimeRing || (unsigned long long)back >= c->launches)
+    return fail(c, NDT_E_ARG, "ndt_kernel_timing: no such launch in the ring");
+  hipEvent_t *evr = c->ev_ring + 3 * ((c->launches - 1 - (unsigned long long)back) % ndt_ctx::kTimeRing);
+  HIP_TRY(c, hipEventSynchronize(evr[2]));
+  float a = 0.f, f = 0.f;
+  HIP_TRY(c, hipEventElapsedTime(&a, evr[0], evr[1]));
+  HIP_TRY(c, hipEventElapsedTime(&f, evr[1], evr[2]));
+  if (match_ms) *match_ms = a;
+  if (fitness_ms) *fitness_ms = f;
   return NDT_OK;
 }
 
@@ -640,7 +664,7 @@ void prof_report(const unsigned long long *hp, int B) {
   }
   fprintf(stderr, "[NDT_PROF] B=%d passes=%.0f (+fitness) | per pass: compute+combine %.2f us, advance %.2f us | shared passes %.0f, helper chunks %.0f, owner wait %.2f us per shared pass | slowest scan %.1f us\n",
           B, ev, te / (ev + B), ta / ev, sh, hc, sh > 0 ? tw / sh : 0.0, worst);
-  if (const char *dump = getenv("NDT_PROF_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(hp, 128, (size_t)B, f); fclose(f); } }
+  if (const char *dump = getenv("NDT_PROF_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(hp, 256, (size_t)B, f); fclose(f); } }
 }
 #endif
 
@@ -686,7 +710,7 @@ int align_host(ndt_ctx *ctx, const ndt_map *map, const float *scans, size_t stri
   unsigned long long *d_prof = nullptr;
 #ifdef NDT_DIAG
   const bool want_prof = getenv("NDT_PROF") != nullptr;
-  if (want_prof) { HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 128)); HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, (size_t)B * 128, st)); }
+  if (want_prof) { HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 256)); HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, (size_t)B * 256, st)); }
 #endif
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
   if ((rc = launch_align(ctx, map, st, (const float *)ctx->d_scan, (const unsigned long long *)ctx->d_off, B,
@@ -696,9 +720,9 @@ int align_host(ndt_ctx *ctx, const ndt_map *map, const float *scans, size_t stri
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
 #ifdef NDT_DIAG
   if (want_prof) {
-    std::vector<unsigned long long> hp((size_t)B * 16);
+    std::vector<unsigned long long> hp((size_t)B * 32);
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    HIP_TRY(ctx, hipMemcpy(hp.data(), d_prof, (size_t)B * 128, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hp.data(), d_prof, (size_t)B * 256, hipMemcpyDeviceToHost));
     prof_report(hp.data(), B);
     hipError_t e = hipFree(d_prof); (void)e;
   }

@@ -2,9 +2,10 @@
 import sys
 import numpy as np
 raw = np.fromfile(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_dump_batch.bin", dtype=np.uint64)
-B = raw.size // 16
+B = raw.size // 32
 hp = raw[:8 * B].reshape(B, 8)
-p2 = raw[8 * B:].reshape(B, 8).astype(np.float64)
+p2 = raw[8 * B:16 * B].reshape(B, 8).astype(np.float64)
+stamps = raw[16 * B:].reshape(B, 16).astype(np.float64) * 0.01
 t_eval = hp[:, 0] * 0.01; t_adv = (hp[:, 1] & 0xFFFFFFFF) * 0.01; t_fit = ((hp[:, 1] >> 32) & 0x7FFFFFFF) * 0.01
 t0 = (hp[:, 2] & 0xFFFFFFFF) * 0.01
 ev = hp[:, 3] & 0xFFFF; nsh = (hp[:, 3] >> 16) & 0xFFFF; nhu = (hp[:, 3] >> 32) & 0x7FFFFFFF
@@ -24,7 +25,13 @@ n = p2[:, 0].sum()
 if n > 0:
     print("shared derivative passes %d: prologue %.2f own units %.2f wait %.2f combine %.2f advance %.2f us (means)" %
           (n, p2[:, 1].sum() / n * 0.01, p2[:, 2].sum() / n * 0.01, p2[:, 3].sum() / n * 0.01, p2[:, 4].sum() / n * 0.01, p2[:, 5].sum() / n * 0.01))
-raw2 = raw[8 * B:].reshape(B, 8)
+raw2 = raw[8 * B:16 * B].reshape(B, 8)
 print("setup phases us (means): region %.1f sort %.1f fill %.1f (marking %.1f, numbering done at %.1f)" % (
     (raw2[:, 6] >> 32).mean() * 0.01, (raw2[:, 6] & 0xFFFFFFFF).mean() * 0.01,
     (raw2[:, 7] >> 32).mean() * 0.01, ((raw2[:, 7] >> 16) & 0xFFFF).mean() * 0.01, (raw2[:, 7] & 0xFFFF).mean() * 0.01))
+names = ["init_state", "region", "sort:histogram", "sort:scan", "sort:scatter", "sort:rank+copy", "publish", "fill:occupancy", "fill:dilate", "fill:number", "fill:records"]
+m = stamps.mean(0)
+print("setup stamps us (mean, cumulative -> delta):")
+prev = 0.0
+for k, nm in enumerate(names):
+    print("  %-16s %6.1f  (+%.1f)" % (nm, m[k], m[k] - prev)); prev = m[k]
