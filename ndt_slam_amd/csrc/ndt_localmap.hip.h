@@ -18,8 +18,14 @@
 //
 // One 1024-thread workgroup per triple does frame, keys, set and difference, the triples of a submap side by
 // side; the neighbour removal and the concatenation then run over 256-point units on the whole chip.
-// Clouds are z = 0 (src/PointCloudMap.cpp:71), so z never leaves the box and has the same key for every
-// point.  (The tests check all of this against a literal two-buffer pointer octree.)
+// Clouds are z = 0 (src/PointCloudMap.cpp:71), so z never leaves the box -- but the box still grows DOWNWARDS in z
+// at every doubling (the child index is built from the upper-bound flags alone), and the z key of a point is
+// (unsigned)((0 - min_z) / resol) in fp64 with the min_z of the moment it was inserted: min_z = -resol (2^depth - 1)
+// accumulates rounding for most values of resol, and the quotient then truncates to 2^depth - 2 in some frames and
+// to 2^depth - 1 in others.  Two points of one (x, y) column inserted at different depths can therefore lie in
+// DIFFERENT leaves; the replay carries min_z and records that deviation per frame, and it is part of the key.
+// (The tests check all of this against a literal two-buffer pointer octree, also at the resolutions where this
+// happens: 0.03, 0.3, 0.02, 0.07.)
 
 constexpr int kMmBlock = 1024, kMmWaves = kMmBlock / 64, kMmEvents = 40, kMmMaxDepth = 30, kMmTile = 1024;
 constexpr int kMmUnit = 256, kMmPer = 4, kMmGroup = 8, kMmIns = 8, kMmLdsTab = 16384;
@@ -42,12 +48,20 @@ struct MmUnit {                        // at most kMmUnit consecutive points of 
 };
 
 struct MmFrame {
-  double minx, miny, maxx, maxy;
+  double minx, miny, maxx, maxy, minz;
   int depth, defined, nev, err, first, from;
   int ev_idx[kMmEvents];
   double ev_minx[kMmEvents], ev_miny[kMmEvents];
   unsigned ev_sx[kMmEvents], ev_sy[kMmEvents];
+  unsigned ev_dz[kMmEvents];           // (2^depth - 1) - z key of a point inserted in this frame: 0 or 1
 };
+
+// z key deviation of the frame whose box starts at minz (genOctreeKeyforPoint's expression for z = 0)
+__device__ inline unsigned mm_dz(double minz, double res, int depth) {
+  const unsigned kz = (unsigned)((0.0 - minz) / res);
+  const unsigned full = (1u << depth) - 1u;
+  return kz <= full ? min(full - kz, 3u) : 3u;
+}
 
 __device__ inline float2 mm_fetch(const MmJob &J, int q) {
   if (q < (int)J.n0) return load_pt(J.a0, J.sa, (size_t)q);
@@ -81,7 +95,9 @@ __device__ inline unsigned long long mm_key(const MmFrame &F, float2 p, int q, d
   }
   const unsigned kx = mm_cell((double)p.x - F.ev_minx[e], res, rinv) + (F.ev_sx[F.nev - 1] - F.ev_sx[e]);
   const unsigned ky = mm_cell((double)p.y - F.ev_miny[e], res, rinv) + (F.ev_sy[F.nev - 1] - F.ev_sy[e]);
-  return ((unsigned long long)kx << 32) | (unsigned long long)ky;
+  // kx, ky < 2^30 (at most 30 tree levels); every later doubling adds the same 2^depth to every z key, so the
+  // frame's deviation is the point's deviation in the final frame
+  return ((unsigned long long)F.ev_dz[e] << 60) | ((unsigned long long)kx << 30) | (unsigned long long)ky;
 }
 
 // order-preserving append of up to kMmPer flagged points per thread (point k of a thread has index
@@ -178,6 +194,12 @@ make_map_diff_kernel(const MmJob *__restrict__ jobs, double res) {
             if (over > (double)FLT_EPSILON) { mn[a] -= over; mx[a] += over; }
           }
           F.minx = mn[0]; F.miny = mn[1]; F.maxx = mx[0]; F.maxy = mx[1];
+          {                                     // the z axis of the same box (z = 0)
+            double mnz = 0.0 - res / 2, mxz = 0.0 + res / 2;
+            const double over = (side - (mxz - mnz)) / 2.0;
+            if (over > (double)FLT_EPSILON) mnz -= over;
+            F.minz = mnz;
+          }
           F.depth = 1; F.defined = 1;
           F.ev_sx[0] = 0u; F.ev_sy[0] = 0u;
         } else if (F.depth >= kMmMaxDepth) {
@@ -188,12 +210,16 @@ make_map_diff_kernel(const MmJob *__restrict__ jobs, double res) {
           unsigned sx = F.ev_sx[e - 1], sy = F.ev_sy[e - 1];
           if (!upx) { F.minx -= side; sx += 1u << F.depth; }
           if (!upy) { F.miny -= side; sy += 1u << F.depth; }
+          F.minz -= side;                       // z = 0 is never at or above max_z: the box always grows downwards in z
           F.depth += 1;
           side = (double)(1 << F.depth) * res - (double)FLT_EPSILON;
           F.maxx = F.minx + side; F.maxy = F.miny + side;
           F.ev_sx[e] = sx; F.ev_sy[e] = sy;
         }
-        if (!F.err) { F.ev_idx[e] = j; F.ev_minx[e] = F.minx; F.ev_miny[e] = F.miny; F.nev = e + 1; }
+        if (!F.err) {
+          F.ev_idx[e] = j; F.ev_minx[e] = F.minx; F.ev_miny[e] = F.miny; F.ev_dz[e] = mm_dz(F.minz, res, F.depth);
+          F.nev = e + 1;
+        }
         F.from = j;                           // the point itself is tested again against the larger box
         F.first = 0x7fffffff;
       }

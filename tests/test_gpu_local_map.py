@@ -45,6 +45,23 @@ def test_difference_extraction_matches_the_octree(ctx, oracle, nb, nt, centre, r
     assert 0 < len(got) <= nt
 
 
+@pytest.mark.parametrize("resol,span", [(0.03, 5.0), (0.3, 20.0), (0.02, 40.0), (0.07, 9.0), (0.03, 60.0), (0.3, 500.0)])
+def test_leaf_sizes_whose_z_key_depends_on_the_frame(ctx, oracle, resol, span):
+    """The octree's z key of a z = 0 point differs between frames of the growing box for these leaf sizes (the
+    `resol` ROS parameter, include/ndt_slam/PCFilter.h:21-23): columns split into two leaves, the difference set
+    grows.  Difference extraction and the whole assembly against the pointer octree."""
+    rng = np.random.default_rng(int(resol * 1000) + int(span))
+    base = (rng.uniform(-span, span, size=(6000, 2))).astype(np.float32)
+    near = base[rng.integers(0, len(base), 2500)] + (rng.normal(size=(2500, 2)) * resol * 0.2).astype(np.float32)
+    test = np.concatenate([near, rng.uniform(-1.5 * span, 1.5 * span, size=(800, 2)).astype(np.float32)])
+    got = ctx.difference_extraction(base, test, resol)
+    assert got.tobytes() == expect_difference(oracle, base, test, resol).tobytes()
+    scans = [base[:3000], test, base[3000:], near[:1500], base[1000:4000]]
+    for first, newest in ((True, True), (False, False)):
+        assert ctx.make_map(scans, first, newest, True, resol, 2.0 * resol).tobytes() == \
+               oracle.make_map(scans, first, newest, True, resol, 2.0 * resol).tobytes()
+
+
 def test_points_on_the_voxel_lattice(ctx, oracle):
     """Coordinates that are exact multiples of the voxel size away from the first point sit on cell borders,
     where the fp64 key of PCL's genOctreeKeyforPoint decides; the box also grows several times in between."""

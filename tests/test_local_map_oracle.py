@@ -29,6 +29,70 @@ def test_octree_matches_lattice(seed):
     assert len(np.unique(idx)) == len(idx)
 
 
+def replay_difference(base, test, r):
+    """The octree's voxel lattice by replaying its bounding-box growth point by point (a second, loop-level
+    statement of adoptBoundingBoxToPoint + genOctreeKeyforPoint in three dimensions, z = 0): every point's key is
+    taken in the frame of the moment it is inserted and moved to the final frame by the shifts of the later
+    doublings.  Returns the indices of the test points whose (x, y, z) key no base point has."""
+    eps = float(np.finfo(np.float32).eps)
+    mn = mx = None
+    depth = 0
+    shift = np.zeros(3, np.int64)
+    recs = []                                  # (key in its frame, shift at insertion)
+    for p in list(base) + list(test):
+        p3 = np.array([float(p[0]), float(p[1]), 0.0])
+        if not np.all(np.isfinite(p3)):
+            recs.append(None)
+            continue
+        while True:
+            if mn is None:
+                mn, mx = p3 - r / 2, p3 + r / 2
+                side = 2.0 * r
+                for a in range(3):
+                    over = (side - (mx[a] - mn[a])) / 2.0
+                    if over > eps:
+                        mn[a] -= over; mx[a] += over
+                depth = 1
+            up = p3 >= mx
+            if not (np.any(p3 < mn) or np.any(up)):
+                break
+            side = float(1 << depth) * r
+            for a in range(3):
+                if not up[a]:
+                    mn[a] -= side; shift[a] += 1 << depth
+            depth += 1
+            mx = mn + (float(1 << depth) * r - eps)
+        recs.append((((p3 - mn) / r).astype(np.int64), shift.copy()))
+    keys = [None if q is None else tuple(q[0] + (shift - q[1])) for q in recs]
+    occ = set(k for k in keys[:len(base)] if k is not None)
+    return np.array([i for i, k in enumerate(keys[len(base):]) if k is not None and k not in occ], dtype=np.int64)
+
+
+@pytest.mark.parametrize("resol,span", [(0.05, 5.0), (0.03, 5.0), (0.3, 20.0), (0.02, 40.0), (0.07, 9.0), (0.013, 3.0)])
+def test_octree_matches_the_frame_replay_in_three_dimensions(resol, span):
+    """For most leaf sizes the z key of a z = 0 point is not the same in every frame of the growing box (min_z
+    accumulates rounding, the fp64 quotient truncates to 2^depth - 2 instead of 2^depth - 1), so points of one
+    (x, y) column inserted at different depths can fall into different leaves -- at 0.03 / 0.3 / 0.02 / 0.07 a
+    lattice in x and y alone disagrees with the octree, the three-dimensional replay does not."""
+    rng = np.random.default_rng(int(resol * 1000))
+    base = (rng.uniform(-span, span, size=(1500, 2))).astype(np.float32)
+    near = base[rng.integers(0, len(base), 600)] + (rng.normal(size=(600, 2)) * resol * 0.2).astype(np.float32)
+    test = np.concatenate([near, rng.uniform(-1.5 * span, 1.5 * span, size=(300, 2)).astype(np.float32)])
+    idx = np.sort(O.difference_indices(base, test, resol))
+    assert np.array_equal(idx, replay_difference(base, test, resol))
+
+
+def test_z_keys_split_columns_at_some_leaf_sizes():
+    """The phenomenon itself: at 0.03 the octree reports more new-voxel points than an (x, y) lattice has."""
+    rng = np.random.default_rng(30)
+    base = (rng.uniform(-5, 5, size=(1500, 2))).astype(np.float32)
+    test = base[rng.integers(0, len(base), 600)] + (rng.normal(size=(600, 2)) * 0.006).astype(np.float32)
+    n3 = len(O.difference_indices(base, test, 0.03))
+    n2 = len(lattice_difference(base, test, 0.03))
+    assert n3 >= n2
+    print("resol 0.03: octree %d new-voxel points, x-y lattice %d" % (n3, n2))
+
+
 def test_octree_order_is_depth_first():
     """The detector walks children in (x, y, z) bit order.  The first test point lies beyond the box in +x and
     +y at every doubling, so the lattice origin stays one cell below the first base point and the new leaves
