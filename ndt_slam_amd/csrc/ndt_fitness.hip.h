@@ -78,7 +78,8 @@ __device__ __forceinline__ float nearest_finish(const MapView &M, float qx, floa
   float best = scan_bucket(M.pts, h.y, h.z, qx, qy, INFINITY);
   // distances from the query to the four walls of its voxel, shrunk by 1e-3 leaf so that a point
   // the float32 voxel rounding put on the other side of a wall is never pruned away
-  const float L = M.leaf, slack = 1e-3f * L;
+  // (the cell of a stored point comes from floorf(x * inv_leaf) in float32: the point can sit |x| 2^-23 beyond the wall)
+  const float L = M.leaf, slack = fmaxf(1e-3f * L, 2.5e-7f * (fabsf(qx) + fabsf(qy) + L));
   const float fx = qx - (float)(cx + M.min_bx) * L, fy = qy - (float)(cy + M.min_by) * L;
   float wl = fmaxf(fx - slack, 0.f), wr = fmaxf(L - fx - slack, 0.f);
   float wd = fmaxf(fy - slack, 0.f), wu = fmaxf(L - fy - slack, 0.f);
