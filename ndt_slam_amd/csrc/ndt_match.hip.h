@@ -154,7 +154,7 @@ __device__ __forceinline__ Window window_of(const Region &R, const uint4 *pool) 
 
 // Owner: bounding box of the scan's voxel coordinates at the first pose -> window geometry.
 template <bool SSE>
-__device__ __forceinline__ void compute_region(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
+__device__ __noinline__ void compute_region(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
                                                int n, Lds &L) {
   if (threadIdx.x == 0) { L.sbox[0] = INT_MAX; L.sbox[1] = INT_MAX; L.sbox[2] = INT_MIN; L.sbox[3] = INT_MIN; }
   __syncthreads();
@@ -211,7 +211,7 @@ __device__ __forceinline__ void compute_region(const MapView &M, const Tf32 &T0,
 // LDS record (centroid -inf).  Sets L.RG.nspill = occupied voxels left without a record.
 // Cells are walked 1024 at a time with consecutive lanes on consecutive cells (coalesced centroid
 // and record reads); the row-major numbering comes from wave ballots kept in LDS.
-__device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool, u64 *stamps = nullptr, u64 t0s = 0) {
+__device__ __noinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool, u64 *stamps = nullptr, u64 t0s = 0) {
   const Region r = L.RG;
   const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
   unsigned short *slot = reinterpret_cast<unsigned short *>(pool);
@@ -388,7 +388,7 @@ __device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *poo
 // Returns false (bitmap still produced, scratch copy not written) when the scan is too large for it.
 constexpr int kSortMax = 20000;             // LDS room for one word per point; point numbers < 2^15
 template <bool SSE>
-__device__ __forceinline__ bool sort_points(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
+__device__ __noinline__ bool sort_points(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
                                             int n, Lds &L, uint4 *pool, float2 *__restrict__ sp,
                                             u64 *stamps = nullptr, u64 t0s = 0) {
   const Region r = L.RG;
@@ -546,11 +546,17 @@ __device__ __forceinline__ const T *uniform_p(const T *p) {
 // compiler spilled inside the point loop (a dozen scratch reloads per point, each behind an s_waitcnt vmcnt(0)).  As a
 // function of its own it is allocated on its own: its inputs come from LDS (g_L.M, g_L.RG, g_L.PP, g_L.pts) and are
 // moved to SGPRs once per call.
+// Two ways of being called (ONE call per wave and pass: a call costs the register saves of the calling convention,
+// scratch stores and loads whose latency a wave pays on its way out):
+//   step == 0: solo pass -- wave `first` walks its own kSub units (first, 0..kSub-1) in one go, totals to L.wpart;
+//   step  > 0: shared pass -- the wave takes units first + j * step (j from the workgroup's LDS counter) until they
+//              reach uend; totals to L.wpart (owner, vtot == nullptr) or straight to the scan's unit totals in HBM.
 template <bool SSE, bool INCL>
-__device__ __noinline__ void pass_units(int w_in, int q0_in, int q1_in, double *__restrict__ dst, int dst_stride_in) {
-  const int w = (int)uniform_u((unsigned)w_in), q0 = (int)uniform_u((unsigned)q0_in), q1 = (int)uniform_u((unsigned)q1_in);
-  const int dst_stride = (int)uniform_u((unsigned)dst_stride_in);
-  const Lds &L = g_L;
+__device__ __noinline__ void pass_units(int first_in, int step_in, int uend_in, u64 *vtot_in) {
+  const int first = (int)uniform_u((unsigned)first_in), step = (int)uniform_u((unsigned)step_in);
+  const int uend = (int)uniform_u((unsigned)uend_in);
+  u64 *const vtot = (u64 *)uniform_p(vtot_in);
+  Lds &L = g_L;
   MapView M;
   M.inv_leaf = uniform_f(L.M.inv_leaf); M.leaf = uniform_f(L.M.leaf); M.r2 = uniform_f(L.M.r2);
   M.radius_inclusive = INCL; M.transform_sse = SSE;
@@ -572,12 +578,26 @@ __device__ __noinline__ void pass_units(int w_in, int q0_in, int q1_in, double *
   PassPose pp;
   pp.T.c = uniform_f(pp_in.T.c); pp.T.s = uniform_f(pp_in.T.s); pp.T.tx = uniform_f(pp_in.T.tx); pp.T.ty = uniform_f(pp_in.T.ty);
   pp.cj = uniform_d(pp_in.cj); pp.sj = uniform_d(pp_in.sj); pp.ch = uniform_d(pp_in.ch); pp.sh = uniform_d(pp_in.sh);
-  const int lane = threadIdx.x & 63, last = n - 1;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, last = n - 1;
   const int per_lane = (n + kBlock - 1) / kBlock;          // points of the longest lane
   const int run = (per_lane + kSub - 1) / kSub;
-  const int kbeg = min(per_lane, q0 * run), kend = min(per_lane, q1 * run);
-  const int base = w * 64 + lane;
-  {
+  for (int it = 0; it <= kUnits; ++it) {                   // counted (tools/repro/ticket2.hip)
+    int w, q0, q1, dst_stride;
+    double *dst;
+    if (step == 0) {
+      if (it > 0) break;
+      w = first; q0 = 0; q1 = kSub; dst = L.wpart + first * 12; dst_stride = kWaves * 12;
+    } else {
+      int j = 0;
+      if (lane == 0) j = atomicAdd(&L.jnext, 1);
+      j = __builtin_amdgcn_readfirstlane(j);
+      const int u = first + j * step;
+      if (u >= uend) break;
+      w = u % kWaves; q0 = u / kWaves; q1 = q0 + 1; dst_stride = 0;
+      dst = vtot ? L.wtmp + wave * 12 : L.wpart + u * 12;
+    }
+    const int kbeg = min(per_lane, q0 * run), kend = min(per_lane, q1 * run);
+    const int base = w * 64 + lane;
     Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
     float2 p0 = gld_f2(pts + min(base + kbeg * kBlock, last)), p1 = gld_f2(pts + min(base + (kbeg + 1) * kBlock, last));
     int q = q0, kb = min(per_lane, (q0 + 1) * run);        // end of the current run
@@ -596,6 +616,13 @@ __device__ __noinline__ void pass_units(int w_in, int q0_in, int q1_in, double *
     }
     for (; q < q1; ++q) {                                  // empty runs (short scans)
       if (lane < 12) dst[(q - q0) * dst_stride + lane] = 0.0;
+    }
+    if (step != 0 && vtot) {                               // helper: publish the unit (write-through stores)
+      const int u = q0 * kWaves + w;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (lane < 12) st64(&vtot[u * 12 + lane], (u64)__double_as_longlong(dst[lane]));
     }
   }
 }
@@ -747,17 +774,10 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         int uend = kUnits;
         if (nhelp <= 0) {
           // solo pass: wave w computes its own units (w, 0..kSub-1) in one walk
-          pass_units<SSE, INCL>(wave, 0, kSub, L.wpart + wave * 12, kWaves * 12);
+          pass_units<SSE, INCL>(wave, 0, kUnits, nullptr);
         } else {
           // this workgroup's units ubeg + j*(nhelp+1), j = 0, 1, ... handed to its waves from an LDS counter
-          for (int it = 0; it <= kUnits; ++it) {             // counted (tools/repro/ticket2.hip)
-            int j = 0;
-            if (lane == 0) j = atomicAdd(&L.jnext, 1);
-            j = __builtin_amdgcn_readfirstlane(j);
-            const int u = ubeg + j * (nhelp + 1);
-            if (u >= kUnits) break;
-            pass_units<SSE, INCL>(u % kWaves, u / kWaves, u / kWaves + 1, L.wpart + u * 12, 0);
-          }
+          pass_units<SSE, INCL>(ubeg, nhelp + 1, kUnits, nullptr);
         }
         if (nhelp > 0) {
           ++epoch;
@@ -984,16 +1004,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       const int h = (int)((word >> 16) & 0xFFu), ubeg = (int)(word & 0xFFu), uend = (int)((word >> 8) & 0xFFu);
       int done_units = 0;
       if (rank < h) {
-        double *wt = L.wtmp + wave * 12;
-        for (int it = 0; it <= kUnits; ++it) {               // this workgroup's units, handed out from an LDS counter
-          int j = 0;
-          if (lane == 0) j = atomicAdd(&L.jnext, 1);
-          j = __builtin_amdgcn_readfirstlane(j);
-          const int u = ubeg + (rank + 1) + j * (h + 1);
-          if (u >= uend) break;
-          pass_units<SSE, INCL>(u % kWaves, u / kWaves, u / kWaves + 1, wt, 0);
-          if (lane < 12) st64(&vtot[u * 12 + lane], (u64)__double_as_longlong(wt[lane]));
-        }
+        // this workgroup's units ubeg + rank+1 + j*(h+1), handed to its waves from an LDS counter
+        pass_units<SSE, INCL>(ubeg + (rank + 1), h + 1, uend, vtot);
         drain_vmem();                                        // the whole wave: its stores have landed
         const int total = uend - ubeg;
         done_units = (total - (rank + 1) + h) / (h + 1);     // units ubeg + rank+1 + j*(h+1) below uend
