@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--config", choices=["C3", "C5"], default="C3",
                     help="C3: 256 scans x 10k vs 1M map per GPU (configs[2]/[3]); C5: 512 seeds x one scan vs 5M map per GPU (configs[4])")
     ap.add_argument("--batch", type=int, default=None, help="matches per GPU and step (default 256 for C3, 512 for C5)")
-    ap.add_argument("--inflight", type=int, default=1, choices=[1, 2], help="match launches in flight (2: alternate two contexts)")
+    ap.add_argument("--inflight", type=int, default=1, choices=[1, 2, 3, 4], help="match launches in flight (k: k contexts / streams in turn, k + 1 map buffers)")
     ap.add_argument("--workgroups", type=int, default=0, help="workgroups per match launch (0 = one per CU); fewer leave CUs to the map build's stream")
     ap.add_argument("--max-helpers", type=int, default=-1, help="helper workgroups per unfinished scan (default: the library's 15); fewer free CUs earlier for the next launch")
     ap.add_argument("--no-scatter", action="store_true", help="N > 1: every rank generates its own shard instead of receiving it from rank 0")
@@ -213,20 +213,21 @@ def main():
     torch.cuda.set_stream(stream)
     prm = capi.default_params(resolution=cfg["resolution"])     # PCL 1.10 preset; otherwise ndt_mapping.launch:32-36
     d_map = torch.from_numpy(map_xy).to(dev)
-    d_res2 = [torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev) for _ in range(2)]
+    nbuf = args.inflight + 1                               # map and result buffers: a step's buffers are free again nbuf steps later
+    d_res2 = [torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     side = torch.cuda.Stream(device=dev) if world > 1 else None      # gather of step i while step i + 1 computes
-    ev_done = [torch.cuda.Event() for _ in range(2)]
-    gathered = [None, None]
+    ev_done = [torch.cuda.Event() for _ in range(nbuf)]
+    gathered = [None] * nbuf
     torch.cuda.synchronize()
     bstream = torch.cuda.Stream(device=dev, priority=-1)     # map builds: small kernels, first in line for freed CUs
     bctx = capi.Context(local_rank)
     bctx.set_stream(bstream.cuda_stream)
-    gmaps = [capi.Map(bctx, params=prm, dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8) for _ in range(2)]
+    gmaps = [capi.Map(bctx, params=prm, dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8) for _ in range(nbuf)]
     gmap = gmaps[0]
     torch.cuda.synchronize()
     solo_build_ms = []
     for _ in range(3):                                      # the build alone, nothing else on the GPU
-        gmaps[1].rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
+        gmaps[-1].rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
         solo_build_ms.append(bctx.last_timing()[0])
     torch.cuda.synchronize()
 
@@ -238,21 +239,23 @@ def main():
     seed_index = (rank + SEED_SHARDS * torch.arange(B, dtype=torch.int64)).to(comm_dev) if c5 else None
 
     def step(i):
-        gm = gmaps[i & 1]
+        gm = gmaps[i % nbuf]
         st, cx = streams[i % args.inflight], mctx[i % args.inflight]
-        # a2: rebuild the voxel grid of this step in place, as soon as the matches of step i - 2 (the last
+        # a2: rebuild the voxel grid of this step in place, as soon as the matches of step i - nbuf (the last
         # readers of this grid) are done
-        if i >= 2:
-            bstream.wait_event(ev_a[2 * (i - 2) + 1])
+        if i >= nbuf:
+            bstream.wait_event(ev_a[2 * (i - nbuf) + 1])
         ev_m[2 * i].record(bstream)
         gm.rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
         ev_m[2 * i + 1].record(bstream)
         # a3-a9 for the whole batch: one launch, after this step's build (the library waits for it too;
         # waiting here keeps that wait out of the kernel's event interval)
         st.wait_event(ev_m[2 * i + 1])
-        out = d_res2[i & 1]
+        out = d_res2[i % nbuf]
+        if i >= nbuf:
+            st.wait_event(ev_a[2 * (i - nbuf) + 1])    # the previous writer of this result buffer (another stream when inflight > 1)
         if world > 1:
-            st.wait_event(ev_done[i & 1])              # the gather that last read this result buffer has finished
+            st.wait_event(ev_done[i % nbuf])           # the gather that last read this result buffer has finished
         ev_a[2 * i].record(st)
         gm.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, total_points, d_init.data_ptr(),
                            out.data_ptr(), shared_scan=c5, stream=st.cuda_stream, ctx=cx)
@@ -260,14 +263,14 @@ def main():
         if world > 1 and not c5:    # gather of poses (the only collective on this path)
             side.wait_stream(st)
             with torch.cuda.stream(side):
-                gathered[i & 1] = shard.gather_results(out if not rehearsal else out.cpu(), dst=0)
-                ev_done[i & 1].record(side)
+                gathered[i % nbuf] = shard.gather_results(out if not rehearsal else out.cpu(), dst=0)
+                ev_done[i % nbuf].record(side)
         if world > 1 and c5:        # configs[4]: arg-max of the hypothesis scores over all ranks (a few bytes)
             side.wait_stream(st)
             with torch.cuda.stream(side):
                 tp = out.view(B, capi.RESULT_BYTES)[:, tp_off:tp_off + 8].contiguous().view(torch.float64).reshape(B)
                 best_log.append(shard.best_hypothesis_t(tp.to(comm_dev), seed_index))    # stays on the device
-                ev_done[i & 1].record(side)
+                ev_done[i % nbuf].record(side)
 
     for i in range(args.warmup):
         step(i)
@@ -292,7 +295,7 @@ def main():
             per_launch.append(cx.kernel_timing(later))
     match_ms = float(np.mean([t[0] for t in per_launch])); fit_ms = float(np.mean([t[1] for t in per_launch]))
     map_ms = [ev_m[2 * i].elapsed_time(ev_m[2 * i + 1]) for i in range(args.warmup, nst)]
-    last = (nst - 1) & 1
+    last = (nst - 1) % nbuf
     res = np.frombuffer(d_res2[last].cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
     assert np.all(res["status"] == 0)
     avg_kern_ms = match_ms                      # the dominant kernel: ndt_align_kernel

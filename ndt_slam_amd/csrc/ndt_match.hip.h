@@ -546,13 +546,16 @@ __device__ __forceinline__ const T *uniform_p(const T *p) {
 // compiler spilled inside the point loop (a dozen scratch reloads per point, each behind an s_waitcnt vmcnt(0)).  As a
 // function of its own it is allocated on its own: its inputs come from LDS (g_L.M, g_L.RG, g_L.PP, g_L.pts) and are
 // moved to SGPRs once per call.
+#ifndef NDT_PASS_INLINE
+#define NDT_PASS_INLINE __noinline__
+#endif
 // Two ways of being called (ONE call per wave and pass: a call costs the register saves of the calling convention,
 // scratch stores and loads whose latency a wave pays on its way out):
 //   step == 0: solo pass -- wave `first` walks its own kSub units (first, 0..kSub-1) in one go, totals to L.wpart;
 //   step  > 0: shared pass -- the wave takes units first + j * step (j from the workgroup's LDS counter) until they
 //              reach uend; totals to L.wpart (owner, vtot == nullptr) or straight to the scan's unit totals in HBM.
 template <bool SSE, bool INCL>
-__device__ __noinline__ void pass_units(int first_in, int step_in, int uend_in, u64 *vtot_in) {
+__device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_in, u64 *vtot_in) {
   const int first = (int)uniform_u((unsigned)first_in), step = (int)uniform_u((unsigned)step_in);
   const int uend = (int)uniform_u((unsigned)uend_in);
   u64 *const vtot = (u64 *)uniform_p(vtot_in);
