@@ -330,3 +330,64 @@ def test_pose_estimator_shim(gpu, oracle, c1_world):
     assert (pose.tx, pose.ty) == (ref["pose"][0], ref["pose"][1])
     assert pose.th == pytest.approx(RAD2DEG(ref["pose"][2]), abs=1e-4 * 180 / math.pi)
     assert cov == pytest.approx(np.linalg.inv(-ref["H"].reshape(3, 3)), rel=1e-6)
+
+
+def test_two_launches_in_flight_and_streams_of_one_context(gpu):
+    """Two contexts, each on its own stream, launch against the same map at the same time (the owners of one batch
+    start on CUs the other's helpers leave): byte-identical records, every repetition.  And two streams on ONE
+    context: the library serialises them on the context's scratch (the second call's stream waits for the first
+    call's kernels), results unchanged."""
+    import torch
+    capi, ctx = gpu
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C3"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    dev = torch.device("cuda", 0)
+    prm = capi.default_params(resolution=cfg["resolution"])
+    gm = capi.Map(ctx, m, prm)
+    batches = []
+    for first, count in ((0, 200), (300, 256)):
+        scans, off, truths, inits = sf.batch(first, count)
+        ref = gm.align_batch(scans, off, inits)
+        batches.append(dict(B=count, n=len(scans), ref=ref.tobytes(),
+                            scans=torch.from_numpy(scans).to(dev), off=torch.from_numpy(off.astype(np.int64)).to(dev),
+                            init=torch.from_numpy(inits).to(dev),
+                            out=torch.zeros(count * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)))
+    ctxs = [capi.Context(0), capi.Context(0)]
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    torch.cuda.synchronize()
+    for rep in range(40):
+        for k, (b, cx, st) in enumerate(zip(batches, ctxs, streams)):
+            b["out"].zero_()
+        torch.cuda.synchronize()
+        for b, cx, st in zip(batches, ctxs, streams):          # both in flight
+            gm.align_batch_dev(b["scans"].data_ptr(), b["off"].data_ptr(), b["B"], b["n"], b["init"].data_ptr(),
+                               b["out"].data_ptr(), stream=st.cuda_stream, ctx=cx)
+        torch.cuda.synchronize()
+        for b in batches:
+            assert b["out"].cpu().numpy().tobytes() == b["ref"], "repetition %d" % rep
+    # one context, two streams, no synchronisation in between
+    for rep in range(10):
+        for b in batches:
+            b["out"].zero_()
+        torch.cuda.synchronize()
+        for b, st in zip(batches, streams):
+            gm.align_batch_dev(b["scans"].data_ptr(), b["off"].data_ptr(), b["B"], b["n"], b["init"].data_ptr(),
+                               b["out"].data_ptr(), stream=st.cuda_stream, ctx=ctxs[0])
+        torch.cuda.synchronize()
+        for b in batches:
+            assert b["out"].cpu().numpy().tobytes() == b["ref"], "one context, repetition %d" % rep
+
+
+def test_map_of_another_device_or_context_is_refused(gpu):
+    capi, ctx = gpu
+    pts = np.random.default_rng(0).uniform(0, 5, (200, 2)).astype(np.float32)
+    other = capi.Context(0)
+    gm = capi.Map(other, pts, capi.default_params(resolution=1.0))
+    with pytest.raises(capi.NdtError):          # a map is rebuilt only by the context that owns it
+        capi.lib()
+        rc = capi.lib().ndt_map_build(ctx.h, pts.ctypes.data, len(pts), 8, __import__("ctypes").byref(gm.params), __import__("ctypes").byref(gm.h))
+        ctx.check(rc, "ndt_map_build")
+    r = gm.align(pts[:50], [0.0, 0.0, 0.0])     # ... but any context of the device may match against it
+    assert int(r["status"]) == 0
