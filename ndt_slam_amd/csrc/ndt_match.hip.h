@@ -1,4 +1,4 @@
-// ndt_match.hip.h -- the match kernel (rows a3-a9): LDS window, spatial sort, units, work sharing between workgroups.
+// ndt_match.hip.h -- the match kernel (rows a3-a6, a8, a9; a7 follows in ndt_fitness.hip.h): LDS window, spatial sort, units, work sharing between workgroups.
 // Part of libndt_mi355x.so: included by ndt_mi355x.hip inside its anonymous namespace (one translation
 // unit; the order of the includes matters).  Not a standalone header.
 
@@ -6,13 +6,13 @@
 // the match kernel
 //
 // One workgroup per CU.  Every scan has an OWNER workgroup that holds the optimiser state in LDS
-// and runs the whole match on the device.  A derivative pass (and the fitness pass) is cut into
+// and runs the whole match on the device.  A derivative pass is cut into
 // kUnits units of points; each unit is reduced on its own and the pass total is the sum of the
 // unit totals in a fixed order, so the result does not depend on who computed which unit.
 // A workgroup whose own scans are finished becomes a HELPER: it attaches to an unfinished scan,
 // stages that scan's window in its own LDS, registers, and from then on computes its static share
 // of the units of every pass the owner opens.  Matches differ widely in the number of passes they
-// need (mean ~12, max ~40 on the bench workload), so without helpers most of the chip idles
+// need (mean ~7, max ~20 on the bench workload), so without helpers most of the chip idles
 // behind the slowest scans.
 //
 // Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16): every shared word (epoch word,
@@ -382,7 +382,7 @@ __device__ __noinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool, 
 // every pass reads.  The 64 lanes of a wave then always work on neighbouring points -- a rigid
 // transform keeps neighbours together, so this holds at every later pose too -- which means: equal
 // in-radius voxel counts (the pair loop runs max-over-lanes times), LDS probes that hit the same few
-// slots and records (broadcast instead of bank conflicts), and in the fitness pass bucket loads that
+// slots and records (broadcast instead of bank conflicts), and in the fitness kernel bucket loads that
 // share cache lines.  The cell histogram also yields the marked-cell bitmap (L.wmap) that
 // fill_window and the helpers use.  Uses the LDS pool as scratch (before the window is staged).
 // Returns false (bitmap still produced, scratch copy not written) when the scan is too large for it.
@@ -739,11 +739,9 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     // ---- derivative passes until the optimiser stops (the fitness score is a kernel of its own: ndt_fitness.hip.h) ----
     while (n > 0 && L.S.phase != PH_DONE) {
       if (kProf && prof) tt0 = wall_clock64();
-      // A pass is run as one or more SEGMENTS of consecutive units.  A derivative pass is one segment:
-      // solo (one walk per wave) or split over the registered helpers.  The fitness pass runs once, can
-      // be long (a poor match walks many rings per point) and usually starts when no helper is free:
-      // solo, its units are handed to the waves one at a time from an LDS counter and the segment is
-      // closed as soon as a helper has registered, so that the rest of the pass is shared.
+      // A pass is one SEGMENT of units [ubeg, uend) = [0, kUnits): solo (one walk per wave) or split over the
+      // registered helpers.  (The epoch word can describe a part of a pass; nothing uses that any more since the
+      // fitness pass -- which was opened solo and re-opened as shared when a helper turned up -- left the kernel.)
       int pass_h = 0, ubeg = 0;
       bool pose_out = false;                       // thread 0: pose block of this pass is in the control block
       for (int seg = 0; seg <= kUnits && ubeg < kUnits; ++seg) {
