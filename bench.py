@@ -403,36 +403,72 @@ def main():
                               "evals": int(r1["evals"]), "single_scan_one_workgroup_ms": solo_ms}
         solo_ctx.close()
 
-    # configs[4] as a side figure of the default run: 512 seeds x one scan vs a 5M-point map (map rebuild + matches)
-    if side_figures and not c5:
-        cfg5 = synth.CONFIGS["C5"]
-        m5 = synth.make_map(cfg5["n_map"], cfg5["half"])
-        sf5 = synth.ScanFactory(m5, cfg5["half"], cfg5["n_scan"])
-        sc5, truth5, _ = sf5.make(0)
-        seeds5 = np.ascontiguousarray(synth.hypothesis_seeds(truth5, cfg5["seeds"])[0::SEED_SHARDS])
-        d_m5 = torch.from_numpy(m5).to(dev); d_s5 = torch.from_numpy(sc5).to(dev)
-        d_o5 = torch.tensor([0, len(sc5)], dtype=torch.int64, device=dev); d_i5 = torch.from_numpy(seeds5).to(dev)
-        d_r5 = torch.zeros(len(seeds5) * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
-        g5 = capi.Map(ctx, params=capi.default_params(resolution=cfg5["resolution"]), dev_ptr=d_m5.data_ptr(), n=len(m5), stride=8)
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        tb, tm = [], []
-        for _ in range(4):
-            e0.record(stream)
-            g5.rebuild(dev_ptr=d_m5.data_ptr(), n=len(m5), stride=8)
-            e1.record(stream)
-            g5.align_batch_dev(d_s5.data_ptr(), d_o5.data_ptr(), len(seeds5), len(sc5), d_i5.data_ptr(), d_r5.data_ptr(),
-                               shared_scan=True, stream=stream.cuda_stream)
-            e2.record(stream)
-            torch.cuda.synchronize()
-            tb.append(e0.elapsed_time(e1)); tm.append(e1.elapsed_time(e2))
-        r5 = np.frombuffer(d_r5.cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
-        b5 = int(np.argmax(r5["trans_prob"]))
-        out["multi_hypothesis"] = {"workload": "configs[4] share of one GPU: %d seeds x one %d-pt scan vs %d-pt map" % (len(seeds5), len(sc5), len(m5)),
-                                   "map_build_ms": float(np.median(tb[1:])), "match_ms": float(np.median(tm[1:])),
-                                   "seeds_per_s": len(seeds5) / (float(np.median(tm[1:])) * 1e-3),
-                                   "mean_evals": float(r5["evals"].mean()), "best_seed_err_m": float(np.hypot(*(r5["pose"][b5][:2] - truth5[:2])))}
-        g5.close()
-        del d_m5, d_r5
+    # configs[4] as a side figure of the default run, on every rank: 512 seeds x one scan vs a 5M-point map (map
+    # rebuild + matches).  At N > 1 this is the whole configs[4] pattern -- the scan broadcast from rank 0, the 4096-seed
+    # lattice cut into strided shards, the arg-max of the scores over all ranks -- so that the driver's multi-GPU run
+    # executes it too; a failure here is reported in the line, it does not take the headline figure down.
+    if not c5 and not args.no_single_scan and (world > 1 or rank == 0):
+        mh = {}
+        try:
+            cfg5 = synth.CONFIGS["C5"]
+            m5 = synth.make_map(cfg5["n_map"], cfg5["half"])
+            n5 = cfg5["n_scan"]
+            if rank == 0:
+                sf5 = synth.ScanFactory(m5, cfg5["half"], n5)
+                sc5, truth5, _ = sf5.make(0)
+                pay = torch.from_numpy(np.concatenate([sc5.ravel().astype(np.float64), truth5])).to(comm_dev)
+            else:
+                pay = torch.empty(2 * n5 + 3, dtype=torch.float64, device=comm_dev)
+            if world > 1:
+                fence()
+                t0 = time.perf_counter()
+                dist.broadcast(pay, src=0)
+                fence()
+                mh["broadcast_scan_ms"] = (time.perf_counter() - t0) * 1e3
+            pay = pay.cpu().numpy()
+            sc5 = pay[:2 * n5].astype(np.float32).reshape(-1, 2); truth5 = pay[2 * n5:]
+            seeds5 = np.ascontiguousarray(synth.hypothesis_seeds(truth5, cfg5["seeds"])[rank::SEED_SHARDS])
+            d_m5 = torch.from_numpy(m5).to(dev); d_s5 = torch.from_numpy(sc5).to(dev)
+            d_o5 = torch.tensor([0, len(sc5)], dtype=torch.int64, device=dev); d_i5 = torch.from_numpy(seeds5).to(dev)
+            d_r5 = torch.zeros(len(seeds5) * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+            g5 = capi.Map(ctx, params=capi.default_params(resolution=cfg5["resolution"]), dev_ptr=d_m5.data_ptr(), n=len(m5), stride=8)
+            e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+            tb, tm, tw = [], [], []
+            gidx = (rank + SEED_SHARDS * torch.arange(len(seeds5), dtype=torch.int64)).to(comm_dev)
+            tpo = capi.RESULT_DTYPE.fields["trans_prob"][1]
+            best_g = None
+            for _ in range(4):
+                fence()
+                t0 = time.perf_counter()
+                e0.record(stream)
+                g5.rebuild(dev_ptr=d_m5.data_ptr(), n=len(m5), stride=8)
+                e1.record(stream)
+                g5.align_batch_dev(d_s5.data_ptr(), d_o5.data_ptr(), len(seeds5), len(sc5), d_i5.data_ptr(), d_r5.data_ptr(),
+                                   shared_scan=True, stream=stream.cuda_stream)
+                e2.record(stream)
+                if world > 1:
+                    with torch.cuda.stream(stream):
+                        tp = d_r5.view(len(seeds5), capi.RESULT_BYTES)[:, tpo:tpo + 8].contiguous().view(torch.float64).reshape(-1)
+                        best_g = shard.best_hypothesis_t(tp.to(comm_dev), gidx)
+                fence()
+                tw.append((time.perf_counter() - t0) * 1e3)
+                tb.append(e0.elapsed_time(e1)); tm.append(e1.elapsed_time(e2))
+            r5 = np.frombuffer(d_r5.cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
+            b5 = int(np.argmax(r5["trans_prob"]))
+            mh.update({"workload": "configs[4]: %d seeds per GPU x %d GPU(s), one %d-pt scan vs %d-pt map" % (len(seeds5), world, len(sc5), len(m5)),
+                       "map_build_ms": float(np.median(tb[1:])), "match_ms": float(np.median(tm[1:])),
+                       "step_wall_ms": float(np.median(tw[1:])),
+                       "seeds_per_s": world * len(seeds5) / (float(np.median(tw[1:])) * 1e-3),
+                       "mean_evals": float(r5["evals"].mean()),
+                       "best_seed_err_m": float(np.hypot(*(r5["pose"][b5][:2] - truth5[:2])))})
+            if best_g is not None:
+                mh["best_over_all_ranks"] = {"trans_prob": float(best_g[0].item()), "seed": int(best_g[1].item())}
+            g5.close()
+            del d_m5, d_r5
+        except Exception as e:                              # noqa: BLE001  (reported, not fatal)
+            mh["error"] = "%s: %s" % (type(e).__name__, e)
+        if rank == 0:
+            out["multi_hypothesis"] = mh
 
     # Row f1 (source pre-filter, pcl::ApproximateVoxelGrid): raw scans 3x oversampled -> filtered scans,
     # all on the device; reported beside the headline metric, not part of it (the 10k-pt scans of the

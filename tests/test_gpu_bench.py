@@ -42,7 +42,7 @@ def test_two_rank_path_walks_through_on_one_gpu():
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"),
                           "--gpus", "2", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True,
-                         text=True, timeout=600)
+                         text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -52,6 +52,9 @@ def test_two_rank_path_walks_through_on_one_gpu():
     assert "scatter from rank 0" in d["config"]["parallelism"] and d["comm"]["scatter_ms"] > 0
     assert len(d["per_rank"]["kernel_ms"]) == 2 and min(d["per_rank"]["kernel_ms"]) > 0
     assert "cpu_baseline" not in d                     # the CPU leg runs at N = 1 only
+    mh = d["multi_hypothesis"]                         # the configs[4] leg of the default run, both ranks
+    assert "error" not in mh, mh
+    assert mh["broadcast_scan_ms"] > 0 and 0 <= mh["best_over_all_ranks"]["seed"] < 4096 and mh["seeds_per_s"] > 0
 
 
 def test_two_rank_multi_hypothesis_path_walks_through_on_one_gpu():
