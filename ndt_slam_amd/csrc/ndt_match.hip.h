@@ -132,14 +132,15 @@ struct Lds {
   unsigned diag[2];                // diagnostic: ticks of fill_window's first two phases
   int clipped;                     // owner: the scan's voxel bounding box did not fit the window
   // what a pass needs besides PP and RG, read by pass_units (a separate function: see there)
-  MapView M;                       // copy of the kernel argument
+  MapView M;                       // copies of the kernel arguments: what the functions around the kernel body read (a
+  OptParams P;                     //   by-value kernel argument whose address is taken is spilled to scratch by every lane)
   const float2 *pts;               // the scan as the passes read it (ordered scratch copy, or the input)
   int npts;
   double etab[64];
 };
 
-// The match kernel's LDS lives at namespace scope so that pass_units -- deliberately NOT inlined into the kernel --
-// can reach it by name: the window pool (slot table + voxel records of one scan) and the control / scratch block.
+// The match kernel's LDS lives at namespace scope so that the routines around the kernel body (pass_units, which can be
+// built as a function of its own) can reach it by name: the window pool (slot table + voxel records of one scan) and the control / scratch block.
 __shared__ Lds g_L;
 __shared__ uint4 g_pool[kPoolBytes / 16];
 
@@ -541,16 +542,19 @@ __device__ __forceinline__ const T *uniform_p(const T *p) {
   return (const T *)(((u64)uniform_u((unsigned)(b >> 32)) << 32) | uniform_u((unsigned)b));
 }
 
-// NOT inlined: the pass loop needs the register file to itself.  Inlined into the kernel (three call sites, each with
-// the LDS and the HBM path of eval_point) it inherited everything the persistent kernel keeps alive around it and the
-// compiler spilled inside the point loop (a dozen scratch reloads per point, each behind an s_waitcnt vmcnt(0)).  As a
-// function of its own it is allocated on its own: its inputs come from LDS (g_L.M, g_L.RG, g_L.PP, g_L.pts) and are
-// moved to SGPRs once per call.
+// The pass loop needs the register file to itself.  In round 1's kernel -- everything inlined into one persistent
+// body, with a dozen 64-bit diagnostic timers alive across every loop -- it inherited what the kernel keeps alive around
+// it and the compiler spilled inside the point loop (a dozen scratch reloads per point, each behind an
+// s_waitcnt vmcnt(0)).  Two things fixed that: the phases AROUND the loop became functions of their own
+// (compute_region, sort_points, fill_window, advance: their registers no longer overlap the loop's), and the loop takes
+// its inputs from LDS (g_L.M, g_L.RG, g_L.PP, g_L.pts), moved to SGPRs once per call, instead of from values that would
+// have to stay live across the whole kernel.  For a while this routine was a function too (-DNDT_PASS_INLINE=__noinline__
+// still builds that): same speed, but every call saved and restored 18 VGPRs per lane through scratch -- 300 MB of
+// write traffic per launch -- so it is inlined again, spill-free now (the kernel's 67 spilled VGPRs are in cold code).
 #ifndef NDT_PASS_INLINE
-#define NDT_PASS_INLINE __noinline__
+#define NDT_PASS_INLINE __forceinline__
 #endif
-// Two ways of being called (ONE call per wave and pass: a call costs the register saves of the calling convention,
-// scratch stores and loads whose latency a wave pays on its way out):
+// Two ways of being used (once per wave and pass):
 //   step == 0: solo pass -- wave `first` walks its own kSub units (first, 0..kSub-1) in one go, totals to L.wpart;
 //   step  > 0: shared pass -- the wave takes units first + j * step (j from the workgroup's LDS counter) until they
 //              reach uend; totals to L.wpart (owner, vtot == nullptr) or straight to the scan's unit totals in HBM.
@@ -664,7 +668,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
   const u64 t_start = kProf ? wall_clock64() : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 64) L.etab[threadIdx.x] = c_exp2_tab[threadIdx.x];
-  if (threadIdx.x == 64) L.M = M;
+  if (threadIdx.x == 64) { L.M = M; L.P = P; }
   bool aborted = false;
 
   // =========================== owner of scans blockIdx.x, + gridDim.x, ... ===========================
@@ -680,7 +684,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     u64 *mytot = utot + (size_t)b * kUnits * 12;
     __syncthreads();
     if (threadIdx.x == 0) {
-      init_state(L.S, P, inits + 3 * (size_t)b, (double)n);
+      init_state(L.S, L.P, inits + 3 * (size_t)b, (double)n);
       if (trace_rows) trace_rows[b] = 0;
       if (n <= 0) { L.S.phase = PH_DONE; L.S.converged = 0; }
     }
@@ -693,10 +697,10 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       NDT_STAMP(stamps, t0s, 0);
       // scratch copy: at the scan's own offsets, or (every match uses scan 0) one slot per match
       float2 *sp = sorted ? (shared_scan ? sorted + (size_t)b * (size_t)n : sorted + o0) : nullptr;
-      compute_region<SSE>(M, L.S.T, scan, n, L);
+      compute_region<SSE>(L.M, L.S.T, scan, n, L);
       const u64 q1 = kProf ? wall_clock64() : 0;
       NDT_STAMP(stamps, t0s, 1);
-      if (sort_points<SSE>(M, L.S.T, scan, n, L, pool, sp, stamps, t0s)) pts = sp;
+      if (sort_points<SSE>(L.M, L.S.T, scan, n, L, pool, sp, stamps, t0s)) pts = sp;
       NDT_STAMP(stamps, t0s, 5);
       const u64 q2 = kProf ? wall_clock64() : 0;
       if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
@@ -722,7 +726,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         }
       }
       NDT_STAMP(stamps, t0s, 6);
-      fill_window(M, L, pool, stamps, t0s);
+      fill_window(L.M, L, pool, stamps, t0s);
       NDT_STAMP(stamps, t0s, 10);
       const u64 q3 = kProf ? wall_clock64() : 0;
       if (kProf && prof && threadIdx.x == 0) {
@@ -828,7 +832,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (kProf && prof) { tt1 = wall_clock64(); }
-        if (lane == 0) advance(L.S, P, M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
+        if (lane == 0) advance(L.S, L.P, L.M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
       }
       // meanwhile another wave fetches the number of registered helpers for the next pass
       if (threadIdx.x == 64 && allow_helpers) L.sflag[1] = (int)rd32_fresh(&C->ready);
@@ -958,7 +962,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     __syncthreads();
     const float2 *pts = L.sflag[1] ? (shared_scan ? sorted + (size_t)vb * (size_t)n : sorted + o0)
                                    : (reinterpret_cast<const float2 *>(scans) + o0);
-    fill_window(M, L, pool);
+    fill_window(L.M, L, pool);
     if (threadIdx.x == 0) { L.pts = pts; L.npts = n; }
     if (kProf && prof && threadIdx.x == 0 && prof[8 * vb + 5] == 0) prof[8 * vb + 5] = wall_clock64() - t_start;
     u64 *vtot = utot + (size_t)vb * kUnits * 12;
