@@ -246,7 +246,7 @@ __device__ __noinline__ void init_state(AlignState &S, const OptParams &P, const
 }
 
 // a9: src/PoseEstimator.cpp:31-35 on the float32 entries; asinf/acosf modelled as correctly rounded.
-__device__ __forceinline__ double yaw_from_T(float T00, float T10) {
+__device__ __noinline__ double yaw_from_T(float T00, float T10) {   // (once per match: kept out of the kernel body, whose loops would hoist its constants into spilled registers)
   if (T00 > 0 && T10 > 0) return (double)(float)asin((double)T10);
   if (T00 > 0 && T10 < 0) return (double)(float)asin((double)T10);
   if (T00 < 0 && T10 > 0) return (double)(float)acos((double)T00);
