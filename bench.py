@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=1, choices=[1, 2, 3, 4], help="match launches in flight (k: k contexts / streams in turn, k + 1 map buffers)")
     ap.add_argument("--workgroups", type=int, default=0, help="workgroups per match launch (0 = one per CU); fewer leave CUs to the map build's stream")
     ap.add_argument("--max-helpers", type=int, default=-1, help="helper workgroups per unfinished scan (default: the library's 15); fewer free CUs earlier for the next launch")
+    ap.add_argument("--time-builds", action="store_true", help="extra events around the map build and around the whole launch inside the step loop (launch_interval_ms, map_build_in_step_ms)")
     ap.add_argument("--no-scatter", action="store_true", help="N > 1: every rank generates its own shard instead of receiving it from rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-scan", action="store_true", help="skip the side figures (configs[1] latency, C5 leg, rows f1-f3)")
@@ -245,7 +246,8 @@ def main():
         # readers of this grid) are done
         if i >= nbuf:
             bstream.wait_event(ev_a[2 * (i - nbuf) + 1])
-        ev_m[2 * i].record(bstream)
+        if args.time_builds:
+            ev_m[2 * i].record(bstream)
         gm.rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
         ev_m[2 * i + 1].record(bstream)
         # a3-a9 for the whole batch: one launch, after this step's build (the library waits for it too;
@@ -256,7 +258,8 @@ def main():
             st.wait_event(ev_a[2 * (i - nbuf) + 1])    # the previous writer of this result buffer (another stream when inflight > 1)
         if world > 1:
             st.wait_event(ev_done[i % nbuf])           # the gather that last read this result buffer has finished
-        ev_a[2 * i].record(st)
+        if args.time_builds:
+            ev_a[2 * i].record(st)                     # (an event record is a packet between two kernels: timing-only ones are optional)
         gm.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, total_points, d_init.data_ptr(),
                            out.data_ptr(), shared_scan=c5, stream=st.cuda_stream, ctx=cx)
         ev_a[2 * i + 1].record(st)                     # (also what the rebuild of step i + 2 waits for)
@@ -285,7 +288,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kern_ms = [ev_a[2 * i].elapsed_time(ev_a[2 * i + 1]) for i in range(args.warmup, nst)]     # all kernels of a launch
+    kern_ms = [ev_a[2 * i].elapsed_time(ev_a[2 * i + 1]) for i in range(args.warmup, nst)] if args.time_builds else None     # all kernels of a launch
     # the library's own events around the match kernel and around the fitness kernels of each launch
     per_launch = []
     for i in range(args.warmup, nst):
@@ -294,14 +297,14 @@ def main():
         if later < 64:
             per_launch.append(cx.kernel_timing(later))
     match_ms = float(np.mean([t[0] for t in per_launch])); fit_ms = float(np.mean([t[1] for t in per_launch]))
-    map_ms = [ev_m[2 * i].elapsed_time(ev_m[2 * i + 1]) for i in range(args.warmup, nst)]
+    map_ms = [ev_m[2 * i].elapsed_time(ev_m[2 * i + 1]) for i in range(args.warmup, nst)] if args.time_builds else None
     last = (nst - 1) % nbuf
     res = np.frombuffer(d_res2[last].cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
     assert np.all(res["status"] == 0)
     avg_kern_ms = match_ms                      # the dominant kernel: ndt_align_kernel
     per_rank = None
     if world > 1:      # per-rank kernel and step figures, so that imbalance across ranks is visible in the SCALE record
-        mine = torch.tensor([avg_kern_ms, float(np.max(kern_ms)), float(res["evals"].sum())], dtype=torch.float64, device=comm_dev)
+        mine = torch.tensor([avg_kern_ms, float(max(t[0] for t in per_launch)), float(res["evals"].sum())], dtype=torch.float64, device=comm_dev)
         allr = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = {"kernel_ms": [float(t[0]) for t in allr], "kernel_ms_max": [float(t[1]) for t in allr],
@@ -340,14 +343,14 @@ def main():
                                  "algorithmic bytes (DESIGN.md 4.7).  The fitness score (N x 16 B per match) is a kernel of its "
                                  "own, listed under `fitness`",
                          "kernel": "ndt_align_kernel", "kernel_ms": avg_kern_ms,
-                         "launch_interval_ms": float(np.mean(kern_ms)),
+                         "launch_interval_ms": float(np.mean(kern_ms)) if kern_ms else None,
                          "fitness": {"kernels": "fitness_points_kernel + fitness_reduce_kernel", "ms": fit_ms,
                                      "algorithmic_bytes_per_launch": fit_bytes,
                                      "achieved_GBps": fit_bytes / (fit_ms * 1e-3) / 1e9 if fit_ms > 0 else None},
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "mean_evals": float(res["evals"].mean()), "max_evals": int(res["evals"].max()),
                          "mean_kbar": float(res["kbar"].mean())},
-            "map_build_ms": float(np.median(solo_build_ms)), "map_build_in_step_ms": float(np.mean(map_ms)),
+            "map_build_ms": float(np.median(solo_build_ms)), "map_build_in_step_ms": float(np.mean(map_ms)) if map_ms else None,
             "converged": int(res["converged"].sum()),
             "accepted": int(accepted.sum()), "accepted_frac": float(accepted.mean()),
         }

@@ -83,7 +83,8 @@ struct ndt_ctx {
   int workgroups = 0;                                  // NDT_OPT_WORKGROUPS: workgroups of a match launch (0: one per CU)
   // The grow-only scratch above belongs to the context, not to a stream: a call on another stream than the
   // previous one first waits for the previous user (ev_scratch).
-  hipEvent_t ev_scratch = nullptr; hipStream_t scratch_stream = nullptr; bool scratch_used = false;
+  hipEvent_t ev_scratch = nullptr; hipStream_t scratch_stream = nullptr; bool scratch_used = false, scratch_recorded = false;
+  size_t ws_clean = 0;                                 // leading bytes of d_ws known to be zero (cleared by the previous launch's last kernel)
   // ring of timing events around the kernels of the last kTimeRing match launches: start, matches done, fitness done
   static constexpr int kTimeRing = 64;
   hipEvent_t ev_ring[3 * kTimeRing] = {};
@@ -145,12 +146,19 @@ int ensure_t(ndt_ctx *ctx, T **p, size_t *cap_elems, size_t need_elems) {
 }
 
 // Scratch hand-over between streams (see ndt_ctx): call before the first and after the last use in an entry point.
+// (An event record is a barrier packet between kernels: a call on the context's own / registered stream -- which lives
+// as long as the registration -- records nothing; the event is recorded on that stream when a call on ANOTHER stream
+// arrives.  A call on a foreign stream records at once: the stream may be gone by the time the next call comes.)
 int scratch_begin(ndt_ctx *ctx, hipStream_t st) {
-  if (ctx->scratch_used && st != ctx->scratch_stream) HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
+  if (ctx->scratch_used && st != ctx->scratch_stream) {
+    if (!ctx->scratch_recorded) HIP_TRY(ctx, hipEventRecord(ctx->ev_scratch, ctx->scratch_stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
+  }
   return NDT_OK;
 }
 int scratch_end(ndt_ctx *ctx, hipStream_t st) {
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_scratch, st));
+  ctx->scratch_recorded = false;
+  if (st != ctx->stream) { HIP_TRY(ctx, hipEventRecord(ctx->ev_scratch, st)); ctx->scratch_recorded = true; }
   ctx->scratch_stream = st; ctx->scratch_used = true;
   return NDT_OK;
 }
@@ -192,8 +200,10 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   // workspace: header + one control line per scan (zeroed every launch) + chunk totals
   const size_t zero_bytes = sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl);
   const size_t ws_bytes = zero_bytes + (size_t)B * kUnits * 12 * sizeof(double) + (size_t)B * (kRegionCells / 8);
+  const size_t ws_cap_before = ctx->d_ws_cap;
   int rc = ensure(ctx, &ctx->d_ws, &ctx->d_ws_cap, ws_bytes);
   if (rc) return rc;
+  if (ctx->d_ws_cap != ws_cap_before) ctx->ws_clean = 0;       // a new allocation
   // ordered copy of every scan (what the passes and the fitness kernel read) and one float per point for the
   // fitness score; when every match uses scan 0 each match has its own slot of the scan's size
   const size_t slots = (shared_scan ? (size_t)B : (size_t)1) * total_points;
@@ -201,7 +211,10 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   if ((rc = ensure(ctx, &ctx->d_fit, &ctx->d_fit_cap, slots * sizeof(float) + 16))) return rc;
   float2 *sorted = (float2 *)ctx->d_sorted;
   float *fit = (float *)ctx->d_fit;
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_ws, 0, zero_bytes, st));
+  // control words: zero before every launch -- by the last kernel of the previous launch of this context
+  // (fitness_reduce_kernel), or by a memset when that did not cover enough
+  if (ctx->ws_clean < zero_bytes) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ws, 0, zero_bytes, st));
+  ctx->ws_clean = 0;
   unsigned char *ws = (unsigned char *)ctx->d_ws;
   const int helpers = ctx->helpers;
   // one workgroup per CU (the LDS window allows no more); idle workgroups help unfinished scans
@@ -225,11 +238,13 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
     const dim3 grid(gx, (unsigned)std::min(B, 65535));
     if (sse) fitness_points_kernel<true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit);
     else     fitness_points_kernel<false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit);
-    fitness_reduce_kernel<<<std::min(B, 4 * ctx->num_cus), kFitBlock, 0, st>>>(offsets, B, shared_scan, fit, out);
+    fitness_reduce_kernel<<<std::min(B, 4 * ctx->num_cus), kFitBlock, 0, st>>>(offsets, B, shared_scan, fit, out,
+                                                                                (unsigned *)ws, (unsigned)(zero_bytes / 4));
   }
   HIP_TRY(ctx, hipEventRecord(evr[2], st));
   ctx->launches++;
   HIP_TRY(ctx, hipGetLastError());
+  ctx->ws_clean = zero_bytes;
   return NDT_OK;
 }
 
@@ -358,6 +373,7 @@ int ndt_ctx_set_stream(ndt_ctx *c, void *stream) {
   if (!c) return NDT_E_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->scratch_used = false;                             // (everything queued so far has finished)
   c->stream = stream ? (hipStream_t)stream : c->own_stream;
   return NDT_OK;
 }

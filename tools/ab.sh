@@ -12,7 +12,7 @@ for spec in "$@"; do
 import json,sys
 try:
     d=json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1]); r=d["roofline"]
-    print("%-50s value %8.0f ms/step %.4f match_ms %.4f fit_ms %.4f frac %.4f evals %.2f build_in_step %.3f" % (sys.argv[2], d["value"], d["ms_per_step"], r["kernel_ms"], r["fitness"]["ms"], r["frac"], r["mean_evals"], d["map_build_in_step_ms"]))
+    print("%-50s value %8.0f ms/step %.4f match_ms %.4f fit_ms %.4f frac %.4f evals %.2f" % (sys.argv[2], d["value"], d["ms_per_step"], r["kernel_ms"], r["fitness"]["ms"], r["frac"], r["mean_evals"]))
 except Exception as e:
     print(sys.argv[2], "no result", e)
 PY
