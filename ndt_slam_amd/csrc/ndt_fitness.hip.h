@@ -197,10 +197,10 @@ constexpr int kFitBlock = 1024, kFitSub = 4;     // = kBlock, kSub of the match 
 __global__ void __launch_bounds__(kFitBlock)
 fitness_reduce_kernel(const unsigned long long *__restrict__ offsets, int B, int shared_scan,
                       const float *__restrict__ fit, ndt_result *__restrict__ results,
-                      unsigned *__restrict__ ws_words, unsigned n_ws_words) {
-  // the last kernel of a launch also clears the match kernel's control words for the next launch (one kernel fewer
-  // between two launches than a memset in front of each)
-  for (unsigned i = blockIdx.x * kFitBlock + threadIdx.x; i < n_ws_words; i += gridDim.x * kFitBlock) ws_words[i] = 0u;
+                      uint4 *__restrict__ ws_words, unsigned n_ws_words) {
+  // the last kernel of a launch also clears the match kernel's control words and epoch-tagged words for the next
+  // launch (one kernel fewer between two launches than a memset in front of each)
+  for (unsigned i = blockIdx.x * kFitBlock + threadIdx.x; i < n_ws_words; i += gridDim.x * kFitBlock) ws_words[i] = uint4{0u, 0u, 0u, 0u};
   __shared__ double U[kFitSub * (kFitBlock / 64) * 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, base = wave * 64 + lane;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {

@@ -15,12 +15,12 @@
 // need (mean ~7, max ~20 on the bench workload), so without helpers most of the chip idles
 // behind the slowest scans.
 //
-// Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16): every shared word (epoch word,
-// arrival counter, ready counter, pose block, unit totals) is read and written ONLY with
-// agent-scope relaxed atomics (sc1 loads / write-through stores), payload stores are drained
-// (s_waitcnt vmcnt(0)) before the word that signals them, and the one bulk hand-off (the owner's
-// ordered scan copy, marked-cell bitmap and window geometry) uses plain stores + agent release
-// fence on the owner and an agent acquire fence on the helper.  No workgroup ever waits for a
+// Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16): every shared word (epoch word, pose halves,
+// unit totals, ready counter) is read and written ONLY with agent-scope relaxed atomics (sc1 loads /
+// write-through stores); the per-pass words validate themselves (payload + epoch tag in one 64-bit word, see
+// ScanCtl), so nothing in a pass is ordered by a flag; the one bulk hand-off (the owner's
+// ordered scan copy, marked-cell bitmap and window geometry) uses plain stores, drained
+// (s_waitcnt vmcnt(0)) + agent release fence on the owner and an agent acquire fence on the helper.  No workgroup ever waits for a
 // workgroup that is not running: a helper is only counted in after it has registered, at which
 // point it does nothing but poll the scan's epoch word; helpers themselves only poll.
 // Every spin is bounded by a watchdog that raises the abort word.
@@ -45,6 +45,17 @@ constexpr int kMaxHelpers = NDT_MAX_HELPERS_BUILD;   // helper workgroups per sc
 #ifndef NDT_BASE_HELPERS
 #define NDT_BASE_HELPERS 7
 #endif
+#ifndef NDT_POLL2
+#define NDT_POLL2 0      // owner: two polls of a unit-total word in flight
+#endif
+#ifndef NDT_POLL2H
+#define NDT_POLL2H 0     // helper: two polls of the epoch line in flight
+#endif
+#ifndef NDT_OWNER_LEAD
+#define NDT_OWNER_LEAD 0
+#endif
+constexpr int kOwnerLead = NDT_OWNER_LEAD;   // units of a shared pass the owner computes on top of its round-robin share
+                                             // (the helpers' share reaches it a hand-off latency after its own)
 constexpr int kBaseHelpers = NDT_BASE_HELPERS;              // ... while more scans are unfinished than workgroups / 8
 constexpr unsigned kEpochDone = 0xFFFFFFFFu;
 constexpr unsigned long long kWatchTicks = 400000000ull;   // ~4 s of the 100 MHz wall clock
@@ -60,31 +71,44 @@ constexpr bool kProf = true;
 constexpr bool kProf = false;
 #endif
 // diagnostic builds: thread 0 of the owner stamps the setup phases of a scan (ticks since the scan was taken)
+// diagnostic builds: timeline of the first kProfPasses shared passes of every scan, 16 words each (absolute ticks):
+// opened, owner's units done, collected, helpers counted in, then (seen, done) of the helpers of rank 0..5
+constexpr int kProfPasses = 24;
+constexpr int kProfTimeline = kProfPasses * 16;
 #define NDT_STAMP(st_, t0_, k_) do { if (kProf && (st_) && threadIdx.x == 0) (st_)[k_] = wall_clock64() - (t0_); } while (0)
 
-// Per-scan control block: four 128-byte lines, so that the words touched by different parties
-// (epoch polls / arrivals / attach + ready counts / pose reads) never share a line.
+// Per-scan control block: two 128-byte lines, so that the words polled by the helpers (line 0, written by the owner
+// only) never share a line with the counters the helpers modify (line 1).
 //
-// The epoch word describes one SEGMENT of a pass -- units [ubeg, uend) split over the owner and the
-// first `h` registered helpers: participant k (0 = owner, k = helper rank + 1) computes the units
+// Every word that hands data from one workgroup to another inside a pass is SELF-VALIDATING: 32 bits of payload under
+// a 32-bit epoch tag, written and read as one aligned 64-bit word (single-copy atomic).  A reader polls the words
+// themselves until each carries the tag of the pass it waits for: no flag that "covers" other stores, hence no drain
+// on the writer and no second, dependent load on the reader -- one one-way latency per direction and pass (round 1 and
+// most of round 2: pose block, drain, epoch word | poll, pose load || totals, drain, arrival add | poll, totals load).
+//   owner -> helpers: line 0 = the epoch word + the twelve 32-bit halves of the pose block of the pass;
+//   helper -> owner : unit totals, 24 words per unit (the halves of its 12 fp64 sums), utot[b][unit][24].
+// Tags are the scan's epoch counter (2, 3, ... one per shared pass); all tagged words are zero at kernel start (cleared
+// by the last kernel of the previous launch, fitness_reduce_kernel, or the memset in front of a first launch).
+//
+// The epoch word describes the split of a pass: units [0, ubeg) are the owner's, units [ubeg, uend) go round-robin over
+// the owner and the first `h` registered helpers -- participant k (0 = owner, k = helper rank + 1) computes the units
 // ubeg + k + j*(h+1).  The assignment is static (no claim atomics: a same-address agent-scope
 // read-modify-write costs ~0.1 us and 128 waves used to queue on it every pass); it is safe because a
-// helper only counts once it has registered in `ready`, after which it does nothing but poll this word.
+// helper only counts once it has registered in `ready`, after which it does nothing but poll line 0.
+constexpr int kPoseWords = 12;               // Tf32 (4 x float32) + cj, sj, ch, sh (4 x fp64) as 32-bit halves
+constexpr int kUnitWords = 24;               // 12 fp64 sums of a unit as 32-bit halves
 struct alignas(128) ScanCtl {
-  u64 ticket;        // line 0: epoch << 32 | h << 16 | uend << 8 | ubeg.  epoch 0: not open; kEpochDone: finished
-  u64 pad0_[15];
-  u32 arrive;        // line 1: units published by helpers in the open epoch (one add per helper workgroup)
-  u32 pad1_[31];
-  u32 helpers;       // line 2: helper workgroups attached; geometry published by the owner's release
+  u64 ticket;        // line 0: epoch << 32 | h << 16 | uend << 8 | ubeg.  epoch 0: not open; 1: open for joining; kEpochDone: finished
+  u64 pose[kPoseWords];   //    epoch << 32 | half k of the pass's PassPose
+  u64 pad0_[3];
+  u32 helpers;       // line 1: helper workgroups attached; geometry published by the owner's release
   int region[6];
   u32 passes;        //         passes the owner has run so far (helpers go where most were needed)
   u32 ready;         //         helpers whose window is staged; rank = order of registration
   u32 use_sorted;    //         1: passes read the scan from the sorted scratch copy
   int pad2_[22];
-  u64 pose[6];       // line 3: float32 transform (c|s, tx|ty) and the four fp64 angle terms
-  u64 pad3_[10];
 };
-static_assert(sizeof(ScanCtl) == 512, "ScanCtl is four 128-byte lines");
+static_assert(sizeof(ScanCtl) == 256, "ScanCtl is two 128-byte lines");
 
 struct WsHeader { u32 done; u32 abort; u32 next; u32 pad[29]; };   // next: scans handed out beyond the first gridDim.x
 static_assert(sizeof(WsHeader) == 128, "WsHeader");
@@ -113,6 +137,8 @@ __device__ __forceinline__ int wave_max_i(int v) {
 
 // pose block of the pass being computed (LDS copy)
 struct PassPose { Tf32 T; double cj, sj, ch, sh; };
+static_assert(offsetof(ScanCtl, pose) == 8 && sizeof(PassPose) == 4 * kPoseWords && offsetof(PassPose, cj) == 16,
+              "line 0 of ScanCtl: the epoch word, then the 32-bit halves of PassPose in memory order");
 
 struct Lds {
   AlignState S;
@@ -121,7 +147,7 @@ struct Lds {
   int sbox[4];
   int swave[kWaves + 1];
   int sflag[4];
-  double wpart[kUnits * 12];       // unit totals this workgroup computed in the open pass
+  double wpart[kUnits * 12];       // unit totals this workgroup computed in the open pass (set-up: marked-cell bitmap + ballots, 4 KiB)
   double wtmp[kWaves * 12];        // helper waves: the unit just computed, before it is published
   double tot[12];                  // pass totals
   unsigned long long own_mask;     // units of the open pass computed by this workgroup
@@ -556,12 +582,14 @@ __device__ __forceinline__ const T *uniform_p(const T *p) {
 #endif
 // Two ways of being used (once per wave and pass):
 //   step == 0: solo pass -- wave `first` walks its own kSub units (first, 0..kSub-1) in one go, totals to L.wpart;
-//   step  > 0: shared pass -- the wave takes units first + j * step (j from the workgroup's LDS counter) until they
-//              reach uend; totals to L.wpart (owner, vtot == nullptr) or straight to the scan's unit totals in HBM.
+//   step  > 0: shared pass -- the wave takes units (j from the workgroup's LDS counter) 0 .. lead-1, then
+//              first + (j - lead) * step until they reach uend; totals to L.wpart (owner, vtot == nullptr) or, tagged,
+//              straight to the scan's unit totals in HBM (helper; lead = 0).
 template <bool SSE, bool INCL>
-__device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_in, u64 *vtot_in) {
+__device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_in, u64 *vtot_in, unsigned tag_in, int lead_in) {
   const int first = (int)uniform_u((unsigned)first_in), step = (int)uniform_u((unsigned)step_in);
-  const int uend = (int)uniform_u((unsigned)uend_in);
+  const int uend = (int)uniform_u((unsigned)uend_in), lead = (int)uniform_u((unsigned)lead_in);
+  const u64 tag = (u64)uniform_u(tag_in) << 32;
   u64 *const vtot = (u64 *)uniform_p(vtot_in);
   Lds &L = g_L;
   MapView M;
@@ -598,7 +626,7 @@ __device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_i
       int j = 0;
       if (lane == 0) j = atomicAdd(&L.jnext, 1);
       j = __builtin_amdgcn_readfirstlane(j);
-      const int u = first + j * step;
+      const int u = j < lead ? j : first + (j - lead) * step;
       if (u >= uend) break;
       w = u % kWaves; q0 = u / kWaves; q1 = q0 + 1; dst_stride = 0;
       dst = vtot ? L.wtmp + wave * 12 : L.wpart + u * 12;
@@ -624,12 +652,15 @@ __device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_i
     for (; q < q1; ++q) {                                  // empty runs (short scans)
       if (lane < 12) dst[(q - q0) * dst_stride + lane] = 0.0;
     }
-    if (step != 0 && vtot) {                               // helper: publish the unit (write-through stores)
-      const int u = q0 * kWaves + w;
+    if (step != 0 && vtot) {                               // helper: publish the unit (write-through stores), each
+      const int u = q0 * kWaves + w;                       // half of a sum under the tag of the pass
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      if (lane < 12) st64(&vtot[u * 12 + lane], (u64)__double_as_longlong(dst[lane]));
+      if (lane < kUnitWords) {
+        const u64 bits = (u64)__double_as_longlong(dst[lane >> 1]);
+        st64(&vtot[u * kUnitWords + lane], tag | (u64)(u32)((lane & 1) ? (bits >> 32) : bits));
+      }
     }
   }
 }
@@ -655,7 +686,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
                  const double *__restrict__ inits, ndt_result *__restrict__ results,
                  double *__restrict__ trace, int trace_cap, int *__restrict__ trace_rows,
                  float2 *__restrict__ sorted /* scratch, same offsets as scans; may be null */,
-                 unsigned char *__restrict__ ws /* WsHeader, ScanCtl[B], unit totals[B][kUnits][12], marked-cell bitmaps[B][kRegionCells/32] */,
+                 unsigned char *__restrict__ ws /* WsHeader, ScanCtl[B], unit totals[B][kUnits][24], marked-cell bitmaps[B][kRegionCells/32] */,
                  int allow_helpers /* 0: none; else max helper workgroups per scan */,
                  unsigned long long *__restrict__ prof /* diagnostic: 8 words per scan */) {
   Lds &L = g_L;
@@ -664,7 +695,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
   ScanCtl *ctl = reinterpret_cast<ScanCtl *>(ws + sizeof(WsHeader));
   u64 *utot = reinterpret_cast<u64 *>(ws + sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl));
   unsigned *wantmap = reinterpret_cast<unsigned *>(ws + sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl) +
-                                                  (size_t)B * kUnits * 12 * sizeof(double));
+                                                  (size_t)B * kUnits * kUnitWords * sizeof(u64));
   const u64 t_start = kProf ? wall_clock64() : 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x < 64) L.etab[threadIdx.x] = c_exp2_tab[threadIdx.x];
@@ -681,7 +712,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     const float2 *scan = reinterpret_cast<const float2 *>(scans) + o0;
     double *tr = trace ? trace + (size_t)b * trace_cap * 8 : nullptr;
     ScanCtl *C = ctl + b;
-    u64 *mytot = utot + (size_t)b * kUnits * 12;
+    u64 *mytot = utot + (size_t)b * kUnits * kUnitWords;
     __syncthreads();
     if (threadIdx.x == 0) {
       init_state(L.S, L.P, inits + 3 * (size_t)b, (double)n);
@@ -734,8 +765,11 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         prof[8 * (size_t)B + 8 * (size_t)b + 7] = ((q3 - q2) << 32) | ((u64)(L.diag[0] & 0xFFFFu) << 16) | (u64)(L.diag[1] & 0xFFFFu);
       }
     }
-    if (threadIdx.x == 0) { L.sflag[1] = 0; L.pts = pts; L.npts = n; }   // sflag[1]: registered helpers (refreshed during every advance)
     unsigned epoch = 1;
+    if (threadIdx.x == 0) {
+      L.sflag[1] = 0; L.pts = pts; L.npts = n;           // sflag[1]: registered helpers (refreshed during every advance)
+      L.sflag[2] = 0;                                    // set by a thread whose wait ran into the watchdog
+    }
     u64 t_eval = 0, t_adv = 0, tt0 = 0, tt1 = 0, t_wait = 0, t_first_shared = 0, t_fit = 0;
     u64 ts1 = 0, ts2 = 0, ts3 = 0, a_pro = 0, a_own = 0, a_wait = 0, a_comb = 0, a_adv = 0, a_n = 0;   // shared derivative passes (diagnostic)
     const u64 t_scan0 = kProf ? wall_clock64() - t_start : 0;
@@ -743,83 +777,89 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     // ---- derivative passes until the optimiser stops (the fitness score is a kernel of its own: ndt_fitness.hip.h) ----
     while (n > 0 && L.S.phase != PH_DONE) {
       if (kProf && prof) tt0 = wall_clock64();
-      // A pass is one SEGMENT of units [ubeg, uend) = [0, kUnits): solo (one walk per wave) or split over the
-      // registered helpers.  (The epoch word can describe a part of a pass; nothing uses that any more since the
-      // fitness pass -- which was opened solo and re-opened as shared when a helper turned up -- left the kernel.)
-      int pass_h = 0, ubeg = 0;
-      bool pose_out = false;                       // thread 0: pose block of this pass is in the control block
-      for (int seg = 0; seg <= kUnits && ubeg < kUnits; ++seg) {
-        if (threadIdx.x == 0) {
-          if (seg == 0) {
-            L.PP.T = L.S.T; L.PP.cj = L.S.cj; L.PP.sj = L.S.sj; L.PP.ch = L.S.ch; L.PP.sh = L.S.sh;
-            if (allow_helpers) st32(&C->passes, (u32)L.S.evals);
-          } else if (allow_helpers) {
-            L.sflag[1] = (int)ld32(&C->ready);
-          }
-          const int h = allow_helpers ? min(L.sflag[1], kMaxHelpers) : 0;
-          L.sflag[0] = h;
-          L.jnext = 0;
-          if (h > 0) {                          // open an epoch: pose block, then the epoch word
-            const PassPose pp = L.PP;
-            if (!pose_out) {
-              pose_out = true;
-              st64(&C->pose[0], ((u64)__float_as_uint(pp.T.s) << 32) | (u64)__float_as_uint(pp.T.c));
-              st64(&C->pose[1], ((u64)__float_as_uint(pp.T.ty) << 32) | (u64)__float_as_uint(pp.T.tx));
-              st64(&C->pose[2], (u64)__double_as_longlong(pp.cj)); st64(&C->pose[3], (u64)__double_as_longlong(pp.sj));
-              st64(&C->pose[4], (u64)__double_as_longlong(pp.ch)); st64(&C->pose[5], (u64)__double_as_longlong(pp.sh));
-            }
-            st32(&C->arrive, 0u);
-            drain_vmem();
-            st64(&C->ticket, ((u64)(epoch + 1) << 32) | ((u64)h << 16) | ((u64)kUnits << 8) | (u64)ubeg);
+      // A pass is solo (one walk per wave) or split over the registered helpers.
+      int pass_h = 0;
+      if (threadIdx.x == 0) {
+        const PassPose pp = {L.S.T, L.S.cj, L.S.sj, L.S.ch, L.S.sh};
+        L.PP = pp;
+        const int h = allow_helpers ? min(L.sflag[1], kMaxHelpers) : 0;
+        L.sflag[0] = h;
+        L.jnext = 0;
+        if (allow_helpers) st32(&C->passes, (u32)L.S.evals);
+        if (h > 0) {                            // open an epoch: the pose halves and the epoch word, all under its tag
+          const u64 tg = (u64)(epoch + 1) << 32;
+          const u64 dj = (u64)__double_as_longlong(pp.cj), ds = (u64)__double_as_longlong(pp.sj);
+          const u64 eh = (u64)__double_as_longlong(pp.ch), es = (u64)__double_as_longlong(pp.sh);
+          st64(&C->pose[0], tg | (u64)__float_as_uint(pp.T.c));  st64(&C->pose[1], tg | (u64)__float_as_uint(pp.T.s));
+          st64(&C->pose[2], tg | (u64)__float_as_uint(pp.T.tx)); st64(&C->pose[3], tg | (u64)__float_as_uint(pp.T.ty));
+          st64(&C->pose[4], tg | (dj & 0xFFFFFFFFull));  st64(&C->pose[5], tg | (dj >> 32));
+          st64(&C->pose[6], tg | (ds & 0xFFFFFFFFull));  st64(&C->pose[7], tg | (ds >> 32));
+          st64(&C->pose[8], tg | (eh & 0xFFFFFFFFull));  st64(&C->pose[9], tg | (eh >> 32));
+          st64(&C->pose[10], tg | (es & 0xFFFFFFFFull)); st64(&C->pose[11], tg | (es >> 32));
+          st64(&C->ticket, tg | ((u64)h << 16) | ((u64)kUnits << 8) | (u64)kOwnerLead);
+          if (kProf && prof && epoch - 1 < (unsigned)kProfPasses) {
+            u64 *tl = prof + 32 * (size_t)B + ((size_t)b * kProfPasses + (epoch - 1)) * 16;
+            tl[0] = wall_clock64(); tl[3] = (u64)h;
           }
         }
-        __syncthreads();
-        if (kProf && prof) ts1 = wall_clock64();
-        const int nhelp = L.sflag[0];
-        int uend = kUnits;
-        if (nhelp <= 0) {
-          // solo pass: wave w computes its own units (w, 0..kSub-1) in one walk
-          pass_units<SSE, INCL>(wave, 0, kUnits, nullptr);
-        } else {
-          // this workgroup's units ubeg + j*(nhelp+1), j = 0, 1, ... handed to its waves from an LDS counter
-          pass_units<SSE, INCL>(ubeg, nhelp + 1, kUnits, nullptr);
-        }
-        if (nhelp > 0) {
-          ++epoch;
-          pass_h = nhelp;
-          __syncthreads();
-          if (kProf && prof) ts2 = wall_clock64();
-          // wait for the helpers' units (every counted helper is polling the epoch word or computing)
-          if (threadIdx.x == 0) {
-            const int total = kUnits - ubeg;
-            const int mine = (total + nhelp) / (nhelp + 1);
-            const u32 need = (u32)(total - mine);
-            int bad = 0; unsigned polls = 0;
-            const u64 w0 = wall_clock64();
-            while (ld32(&C->arrive) < need) {
-              if (watchdog(hdr, w0, polls)) { bad = 1; break; }
-              __builtin_amdgcn_s_sleep(2);
-            }
-            if (kProf) { t_wait += wall_clock64() - w0; if (n_shared == 0) t_first_shared = w0 - t_start; n_shared += 1; n_helped += need; }
-            L.sflag[2] = bad;
-          }
-          __syncthreads();
-          if (kProf && prof) ts3 = wall_clock64();
-          if (L.sflag[2]) { aborted = true; break; }
-          // helpers' totals of this segment: one load per lane, in flight together
-          if (threadIdx.x < (kUnits - ubeg) * 12) {
-            const int u = ubeg + threadIdx.x / 12;
-            if ((u - ubeg) % (nhelp + 1) != 0)
-              L.wpart[ubeg * 12 + threadIdx.x] = __longlong_as_double((long long)ld64(&mytot[ubeg * 12 + threadIdx.x]));
-          }
-        }
-        __syncthreads();
-        ubeg = uend;
       }
-      if (aborted) break;
+      __syncthreads();
+      if (kProf && prof) ts1 = wall_clock64();
+      const int nhelp = L.sflag[0];
+      if (nhelp <= 0) {
+        // solo pass: wave w computes its own units (w, 0..kSub-1) in one walk
+        pass_units<SSE, INCL>(wave, 0, kUnits, nullptr, 0u, 0);
+      } else {
+        // this workgroup's units 0 .. kOwnerLead-1 and kOwnerLead + j*(nhelp+1), handed to its waves from an LDS counter
+        ++epoch;
+        pass_h = nhelp;
+        pass_units<SSE, INCL>(kOwnerLead, nhelp + 1, kUnits, nullptr, 0u, kOwnerLead);
+        if (kProf && prof) ts2 = wall_clock64();
+        // the helpers' units: every thread polls the words it will copy (24 per unit) until they carry this epoch's
+        // tag (every counted helper is polling the epoch word or computing)
+        u32 *const wp32 = reinterpret_cast<u32 *>(L.wpart);
+        unsigned polls = 0;
+        u64 w0 = 0;
+        bool bad = false;
+        for (int wi = threadIdx.x; wi < kUnits * kUnitWords && !bad; wi += kBlock) {
+          const int u = wi / kUnitWords;
+          if (u < kOwnerLead || (u - kOwnerLead) % (nhelp + 1) == 0) continue;      // own unit
+#if NDT_POLL2
+          u64 w = 0, w_next = ld64(&mytot[wi]);          // two polls in flight: half the time between looks
+#else
+          u64 w = 0;
+#endif
+          for (unsigned it = 0; it < 0x40000000u; ++it) {
+#if NDT_POLL2
+            w = w_next;
+            w_next = ld64(&mytot[wi]);
+#else
+            w = ld64(&mytot[wi]);
+#endif
+            if ((u32)(w >> 32) == epoch) break;
+            if ((++polls & 63u) == 0u) {           // bound on the spin, as in watchdog(); the clock is read lazily
+              if (ld32(&hdr->abort)) { bad = true; break; }
+              if (w0 == 0) w0 = wall_clock64();
+              else if (wall_clock64() - w0 > kWatchTicks) { st32(&hdr->abort, 1u); bad = true; break; }
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          wp32[wi] = (u32)w;
+        }
+        if (bad) L.sflag[2] = 1;
+        if (kProf && threadIdx.x == 0) { if (n_shared == 0) t_first_shared = ts2 - t_start; n_shared += 1; }
+      }
+      __syncthreads();
+      if (kProf && prof) ts3 = wall_clock64();
+      if (kProf && prof && threadIdx.x == 0 && pass_h > 0 && epoch - 2 < (unsigned)kProfPasses) {
+        u64 *tl = prof + 32 * (size_t)B + ((size_t)b * kProfPasses + (epoch - 2)) * 16;
+        tl[1] = ts2; tl[2] = ts3;
+      }
+      if (L.sflag[2]) { aborted = true; break; }
       // pass total: the units in kSub groups of 16, each summed in unit order by one lane per value,
       // then the partial sums in group order; wave 0 goes straight on to the optimiser step
       static_assert(kSub * 12 <= 64 && kUnits == 16 * kSub, "one lane per (group, value)");
+      static_assert(sizeof(L.wpart) >= 4096, "the set-up phases keep 4 KiB of bitmaps in L.wpart");
       if (threadIdx.x < 64) {
         const int j = lane % 12, grp = lane / 12;             // lanes kSub*12..63: nothing to add
         double part = 0.0;
@@ -965,7 +1005,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     fill_window(L.M, L, pool);
     if (threadIdx.x == 0) { L.pts = pts; L.npts = n; }
     if (kProf && prof && threadIdx.x == 0 && prof[8 * vb + 5] == 0) prof[8 * vb + 5] = wall_clock64() - t_start;
-    u64 *vtot = utot + (size_t)vb * kUnits * 12;
+    u64 *vtot = utot + (size_t)vb * kUnits * kUnitWords;
     // register: from now on this workgroup does nothing but watch the scan's epoch word
     if (threadIdx.x == 0) L.hrank = (int)__hip_atomic_fetch_add(&C->ready, 1u, NDT_RLX, NDT_AGENT);
     __syncthreads();
@@ -973,33 +1013,35 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     u32 last_ep = 0;
     for (unsigned turns = 0; turns < 0x40000000u; ++turns) {         // counted (tools/repro/ticket2.hip)
       if (wave == 0) {
-        // wave 0 polls the epoch word (one load in flight per helper workgroup on the owner's line)
-        u64 word = 0;
-        if (lane == 0) {
-          unsigned polls = 0;
-          const u64 w0 = wall_clock64();
-          for (unsigned it = 0; it < 0x40000000u; ++it) {
-            word = ld64(&C->ticket);
-            if ((u32)(word >> 32) != last_ep && (u32)(word >> 32) != 0u) break;
-            if (watchdog(hdr, w0, polls)) { word = (u64)kEpochDone << 32; break; }
-            __builtin_amdgcn_s_sleep(1);
+        // wave 0 polls line 0 of the scan's control block: lane 0 the epoch word, lanes 1..12 the pose halves.  A new
+        // epoch that counts this helper in is taken once every pose word carries its tag as well.
+        u64 word = 0, mine = 0, mine_next = 0;
+        unsigned polls = 0;
+        const u64 w0 = wall_clock64();
+#if NDT_POLL2H
+        if (lane <= kPoseWords) mine_next = ld64(&C->ticket + lane);   // two polls in flight: half the time between looks
+#endif
+        for (unsigned it = 0; it < 0x40000000u; ++it) {
+#if NDT_POLL2H
+          mine = mine_next;
+          if (lane <= kPoseWords) mine_next = ld64(&C->ticket + lane);
+#else
+          if (lane <= kPoseWords) mine = ld64(&C->ticket + lane);
+#endif
+          word = wave_bcast64(mine);
+          const u32 ep = (u32)(word >> 32);
+          if (ep != last_ep && ep != 0u) {
+            if (ep == kEpochDone || rank >= (int)((word >> 16) & 0xFFu)) break;
+            if (__builtin_amdgcn_ballot_w64(lane <= kPoseWords && (u32)(mine >> 32) != ep) == 0ull) break;
           }
+          if (watchdog(hdr, w0, polls)) { word = (u64)kEpochDone << 32; break; }
+          __builtin_amdgcn_s_sleep(1);
         }
-        word = wave_bcast64(word);
-        const int h = (int)((word >> 16) & 0xFFu);
-        if ((u32)(word >> 32) != kEpochDone && rank < h) {   // the pose block is stable: this helper is counted in
-          u64 pw = 0;
-          if (lane < 6) pw = ld64(&C->pose[lane]);
-          const u64 w0 = __shfl(pw, 0), w1 = __shfl(pw, 1);
-          if (lane == 0) {
-            struct { Tf32 T; } q;
-            q.T.c = __uint_as_float((u32)w0); q.T.s = __uint_as_float((u32)(w0 >> 32));
-            q.T.tx = __uint_as_float((u32)w1); q.T.ty = __uint_as_float((u32)(w1 >> 32));
-            L.PP.T = q.T;
-          }
-          if (lane >= 2 && lane < 6) (&L.PP.cj)[lane - 2] = __longlong_as_double((long long)pw);   // cj, sj, ch, sh
-        }
+        if ((u32)(word >> 32) != kEpochDone && rank < (int)((word >> 16) & 0xFFu) && lane >= 1 && lane <= kPoseWords)
+          reinterpret_cast<u32 *>(&L.PP)[lane - 1] = (u32)mine;      // T.c, T.s, T.tx, T.ty, then the halves of cj, sj, ch, sh
         if (lane == 0) { L.hword = word; L.jnext = 0; }
+        if (kProf && prof && lane == 0 && rank < 6 && rank < (int)((word >> 16) & 0xFFu) && (u32)(word >> 32) - 2u < (unsigned)kProfPasses)
+          prof[32 * (size_t)B + ((size_t)vb * kProfPasses + ((u32)(word >> 32) - 2u)) * 16 + 4 + 2 * rank] = wall_clock64();
       }
       __syncthreads();
       const u64 word = L.hword;
@@ -1007,17 +1049,13 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       if (ep == kEpochDone) break;
       last_ep = ep;
       const int h = (int)((word >> 16) & 0xFFu), ubeg = (int)(word & 0xFFu), uend = (int)((word >> 8) & 0xFFu);
-      int done_units = 0;
       if (rank < h) {
         // this workgroup's units ubeg + rank+1 + j*(h+1), handed to its waves from an LDS counter
-        pass_units<SSE, INCL>(ubeg + (rank + 1), h + 1, uend, vtot);
-        drain_vmem();                                        // the whole wave: its stores have landed
-        const int total = uend - ubeg;
-        done_units = (total - (rank + 1) + h) / (h + 1);     // units ubeg + rank+1 + j*(h+1) below uend
-        if (done_units < 0) done_units = 0;
+        pass_units<SSE, INCL>(ubeg + (rank + 1), h + 1, uend, vtot, ep, 0);
       }
-      __syncthreads();
-      if (threadIdx.x == 0 && done_units > 0) __hip_atomic_fetch_add(&C->arrive, (u32)done_units, NDT_RLX, NDT_AGENT);
+      __syncthreads();                                       // L.jnext / L.PP are rewritten by wave 0 in the next turn
+      if (kProf && prof && threadIdx.x == 0 && rank < 6 && rank < h && ep - 2u < (unsigned)kProfPasses)
+        prof[32 * (size_t)B + ((size_t)vb * kProfPasses + (ep - 2u)) * 16 + 5 + 2 * rank] = wall_clock64();
     }
   }
 }

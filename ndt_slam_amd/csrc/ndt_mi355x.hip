@@ -198,8 +198,9 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   const MapView &V = map->view;
   const OptParams O = opt_of(map->prm);
   // workspace: header + one control line per scan (zeroed every launch) + chunk totals
-  const size_t zero_bytes = sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl);
-  const size_t ws_bytes = zero_bytes + (size_t)B * kUnits * 12 * sizeof(double) + (size_t)B * (kRegionCells / 8);
+  // control words, epoch-tagged pose halves and unit totals (zero at kernel start), then the marked-cell bitmaps
+  const size_t zero_bytes = sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl) + (size_t)B * kUnits * kUnitWords * sizeof(u64);
+  const size_t ws_bytes = zero_bytes + (size_t)B * (kRegionCells / 8);
   const size_t ws_cap_before = ctx->d_ws_cap;
   int rc = ensure(ctx, &ctx->d_ws, &ctx->d_ws_cap, ws_bytes);
   if (rc) return rc;
@@ -239,7 +240,7 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
     if (sse) fitness_points_kernel<true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit);
     else     fitness_points_kernel<false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit);
     fitness_reduce_kernel<<<std::min(B, 4 * ctx->num_cus), kFitBlock, 0, st>>>(offsets, B, shared_scan, fit, out,
-                                                                                (unsigned *)ws, (unsigned)(zero_bytes / 4));
+                                                                                (uint4 *)ws, (unsigned)(zero_bytes / 16));
   }
   HIP_TRY(ctx, hipEventRecord(evr[2], st));
   ctx->launches++;
@@ -680,7 +681,7 @@ void prof_report(const unsigned long long *hp, int B) {
   }
   fprintf(stderr, "[NDT_PROF] B=%d passes=%.0f (+fitness) | per pass: compute+combine %.2f us, advance %.2f us | shared passes %.0f, helper chunks %.0f, owner wait %.2f us per shared pass | slowest scan %.1f us\n",
           B, ev, te / (ev + B), ta / ev, sh, hc, sh > 0 ? tw / sh : 0.0, worst);
-  if (const char *dump = getenv("NDT_PROF_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(hp, 256, (size_t)B, f); fclose(f); } }
+  if (const char *dump = getenv("NDT_PROF_DUMP")) { FILE *f = fopen(dump, "wb"); if (f) { fwrite(hp, 256 + kProfTimeline * 8, (size_t)B, f); fclose(f); } }
 }
 #endif
 
@@ -726,7 +727,8 @@ int align_host(ndt_ctx *ctx, const ndt_map *map, const float *scans, size_t stri
   unsigned long long *d_prof = nullptr;
 #ifdef NDT_DIAG
   const bool want_prof = getenv("NDT_PROF") != nullptr;
-  if (want_prof) { HIP_TRY(ctx, hipMalloc(&d_prof, (size_t)B * 256)); HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, (size_t)B * 256, st)); }
+  const size_t prof_bytes = (size_t)B * (256 + kProfTimeline * 8);      // phase timers, then the shared-pass timelines
+  if (want_prof) { HIP_TRY(ctx, hipMalloc(&d_prof, prof_bytes)); HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, prof_bytes, st)); }
 #endif
   HIP_TRY(ctx, hipEventRecord(ctx->ev0, st));
   if ((rc = launch_align(ctx, map, st, (const float *)ctx->d_scan, (const unsigned long long *)ctx->d_off, B,
@@ -736,9 +738,9 @@ int align_host(ndt_ctx *ctx, const ndt_map *map, const float *scans, size_t stri
   HIP_TRY(ctx, hipEventRecord(ctx->ev1, st));
 #ifdef NDT_DIAG
   if (want_prof) {
-    std::vector<unsigned long long> hp((size_t)B * 32);
+    std::vector<unsigned long long> hp(prof_bytes / 8);
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    HIP_TRY(ctx, hipMemcpy(hp.data(), d_prof, (size_t)B * 256, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(hp.data(), d_prof, prof_bytes, hipMemcpyDeviceToHost));
     prof_report(hp.data(), B);
     hipError_t e = hipFree(d_prof); (void)e;
   }

@@ -7,7 +7,7 @@ for spec in "$@"; do
   lib="${spec%%|*}"; flags="${spec#*|}"
   i=$((i+1))
   if [ -n "$lib" ]; then export NDT_LIB_PATH=$PWD/$lib; else unset NDT_LIB_PATH; fi
-  timeout -k 10 240 python3 bench.py --no-single-scan --no-cpu-baseline $flags > $OUT/ab_$i.log 2> $OUT/ab_$i.err || { echo "spec $i failed"; tail -5 $OUT/ab_$i.err; }
+  timeout -k 10 240 python3 bench.py --no-single-scan --no-cpu-baseline $flags > $OUT/ab_$i.log 2> $OUT/ab_$i.err || { echo "spec $i failed"; tail -5 $OUT/ab_$i.err; exit 1; }
   python3 - "$OUT/ab_$i.log" "$spec" <<'PY'
 import json,sys
 try:

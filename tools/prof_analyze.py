@@ -2,10 +2,11 @@
 import sys
 import numpy as np
 raw = np.fromfile(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof_dump_batch.bin", dtype=np.uint64)
-B = raw.size // 32
+PASSES = 24                                  # kProfPasses: shared-pass timelines behind the 32 words per scan
+B = raw.size // (32 + PASSES * 16)
 hp = raw[:8 * B].reshape(B, 8)
 p2 = raw[8 * B:16 * B].reshape(B, 8).astype(np.float64)
-stamps = raw[16 * B:].reshape(B, 16).astype(np.float64) * 0.01
+stamps = raw[16 * B:32 * B].reshape(B, 16).astype(np.float64) * 0.01
 t_eval = hp[:, 0] * 0.01; t_adv = (hp[:, 1] & 0xFFFFFFFF) * 0.01; t_fit = ((hp[:, 1] >> 32) & 0x7FFFFFFF) * 0.01
 t0 = (hp[:, 2] & 0xFFFFFFFF) * 0.01
 ev = hp[:, 3] & 0xFFFF; nsh = (hp[:, 3] >> 16) & 0xFFFF; nhu = (hp[:, 3] >> 32) & 0x7FFFFFFF
@@ -35,3 +36,25 @@ print("setup stamps us (mean, cumulative -> delta):")
 prev = 0.0
 for k, nm in enumerate(names):
     print("  %-16s %6.1f  (+%.1f)" % (nm, m[k], m[k] - prev)); prev = m[k]
+
+# ---- timelines of the shared passes (absolute 100 MHz ticks): opened, own units done, collected, h, (seen, done) x 6
+tl = raw[32 * B:].reshape(B, PASSES, 16).astype(np.int64)
+ok = (tl[:, :, 0] > 0) & (tl[:, :, 2] > 0)
+print("shared passes with a timeline:", int(ok.sum()))
+rows = []
+for b, k in zip(*np.nonzero(ok)):
+    t = tl[b, k]; h = int(t[3])
+    seen = [t[4 + 2 * r] - t[0] for r in range(min(h, 6)) if t[4 + 2 * r] > 0]
+    done = [t[5 + 2 * r] - t[0] for r in range(min(h, 6)) if t[5 + 2 * r] > 0]
+    if not seen or not done:
+        continue
+    rows.append((h, (t[1] - t[0]) * 0.01, (t[2] - t[0]) * 0.01, min(seen) * 0.01, max(seen) * 0.01, max(done) * 0.01,
+                 np.mean([d - s for s, d in zip(seen, done)]) * 0.01))
+rows = np.array(rows)
+if len(rows):
+    print("  h | passes | owner done | collected | helper sees (first/last) | last helper done | helper compute | collected - last done")
+    for h in sorted(set(rows[:, 0].astype(int))):
+        r = rows[rows[:, 0] == h]
+        print("  %2d | %5d | %6.2f | %6.2f | %5.2f / %5.2f | %6.2f | %6.2f | %5.2f" % (
+            h, len(r), r[:, 1].mean(), r[:, 2].mean(), r[:, 3].mean(), r[:, 4].mean(), r[:, 5].mean(), r[:, 6].mean(),
+            (r[:, 2] - r[:, 5]).mean()))
