@@ -250,12 +250,11 @@ def main():
             ev_m[2 * i].record(bstream)
         gm.rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
         ev_m[2 * i + 1].record(bstream)
-        # a3-a9 for the whole batch: one launch, after this step's build (the library waits for it too;
-        # waiting here keeps that wait out of the kernel's event interval)
-        st.wait_event(ev_m[2 * i + 1])
+        # a3-a9 for the whole batch: one launch, after this step's build (the library makes the match stream wait
+        # for the build of the map it is given: no second wait here -- every wait is a packet between two kernels)
         out = d_res2[i % nbuf]
-        if i >= nbuf:
-            st.wait_event(ev_a[2 * (i - nbuf) + 1])    # the previous writer of this result buffer (another stream when inflight > 1)
+        if i >= nbuf and args.inflight > 1:
+            st.wait_event(ev_a[2 * (i - nbuf) + 1])    # the previous writer of this result buffer: another stream when inflight > 1
         if world > 1:
             st.wait_event(ev_done[i % nbuf])           # the gather that last read this result buffer has finished
         if args.time_builds:

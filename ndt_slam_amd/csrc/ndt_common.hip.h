@@ -74,6 +74,16 @@ __device__ __forceinline__ float4 gld_f4(const float4 *p) {
   const ndt_f4v v = *(const NDT_GLOBAL ndt_f4v *)p;
   return make_float4(v.x, v.y, v.z, v.w);
 }
+// the same at a 32-bit byte offset from a wave-uniform base: global_load vdst, voffset, s[base] -- one VALU
+// instruction per address instead of three (sign extension + 64-bit add) when a lane walks its own range
+__device__ __forceinline__ float2 gld_f2_at(const void *base, unsigned byte_off) {
+  const ndt_f2v v = *(const NDT_GLOBAL ndt_f2v *)((const NDT_GLOBAL char *)base + byte_off);
+  return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float4 gld_f4_at(const void *base, unsigned byte_off) {
+  const ndt_f4v v = *(const NDT_GLOBAL ndt_f4v *)((const NDT_GLOBAL char *)base + byte_off);
+  return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ double2 gld_d2(const double *p) {
   const ndt_d2v v = *(const NDT_GLOBAL ndt_d2v *)p;
   return make_double2(v.x, v.y);

@@ -36,16 +36,18 @@ __device__ __forceinline__ float scan_bucket(const float2 *__restrict__ pts, int
                                              float qy, float best) {
   if (s >= se) return best;
   if (s & 1) { const float2 p = gld_f2(pts + s); best = fminf(best, sq_dist(qx, qy, p.x, p.y)); ++s; }
-  const float4 *__restrict__ p4 = reinterpret_cast<const float4 *>(pts + s);   // 16-byte aligned
-  const int npair = (se - s) >> 1;
-  for (int i = 0; i < npair; i += kFitWide) {
-    float4 v[kFitWide];
+  // pairs of points, 16-byte aligned, addressed by 32-bit byte offsets from the (uniform) array base; a load past the
+  // end of the bucket re-reads its last pair -- the minimum does not care about a point seen twice, so nothing is masked
+  const unsigned npair = (unsigned)(se - s) >> 1, first = (unsigned)s * 8u;
+  if (npair) {
+    const unsigned last = first + (npair - 1u) * 16u;
+    for (unsigned i = 0; i < npair; i += kFitWide) {
+      float4 v[kFitWide];
 #pragma unroll
-    for (int u = 0; u < kFitWide; ++u) v[u] = gld_f4(p4 + min(i + u, npair - 1));
+      for (int u = 0; u < kFitWide; ++u) v[u] = gld_f4_at(pts, min(first + (i + u) * 16u, last));
 #pragma unroll
-    for (int u = 0; u < kFitWide; ++u) {
-      const float d = fminf(sq_dist(qx, qy, v[u].x, v[u].y), sq_dist(qx, qy, v[u].z, v[u].w));
-      best = fminf(best, (i + u < npair) ? d : INFINITY);
+      for (int u = 0; u < kFitWide; ++u)
+        best = fminf(best, fminf(sq_dist(qx, qy, v[u].x, v[u].y), sq_dist(qx, qy, v[u].z, v[u].w)));
     }
   }
   if ((se - s) & 1) { const float2 p = gld_f2(pts + se - 1); best = fminf(best, sq_dist(qx, qy, p.x, p.y)); }
@@ -114,13 +116,12 @@ __device__ __forceinline__ float nearest_finish(const MapView &M, float qx, floa
       float2 v[kRingWide];
 #pragma unroll
       for (int u = 0; u < kRingWide; ++u) {
-        const int t = min(t0 + u, total - 1);
+        const int t = min(t0 + u, total - 1);            // past the end: the last point again (harmless for a minimum)
         const int off = t < c1 ? o0 : (t < c2 ? o1 : (t < c3 ? o2 : o3));
-        v[u] = gld_f2(M.pts + (off + t));
+        v[u] = gld_f2_at(M.pts, (unsigned)(off + t) * 8u);
       }
 #pragma unroll
-      for (int u = 0; u < kRingWide; ++u)
-        best = fminf(best, (t0 + u < total) ? sq_dist(qx, qy, v[u].x, v[u].y) : INFINITY);
+      for (int u = 0; u < kRingWide; ++u) best = fminf(best, sq_dist(qx, qy, v[u].x, v[u].y));
     }
   }
   const double Ld = (double)L;
