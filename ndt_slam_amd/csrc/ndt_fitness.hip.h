@@ -72,10 +72,23 @@ __device__ __forceinline__ NearPrep nearest_prep(const MapView &M, float qx, flo
   return P;
 }
 
-__device__ __forceinline__ float nearest_finish(const MapView &M, float qx, float qy, const NearPrep &P) {
+// State of one query between the phases of the search.
+struct NearState {
+  float best;                     // squared distance to the nearest point seen so far
+  int cx, cy;                     // home voxel (clamped into the grid)
+  float wl, wr, wd, wu;           // distances to the walls of the home voxel (shrunk by the rounding slack; 0 if clamped)
+  bool more;                      // another voxel can still hold a closer point
+  int rs[4], rn[4];               // ring 1 as (up to) four ranges of the bucketed points: start, length
+};
+
+// Phase 1: the home voxel, then which ring-1 voxels can still matter -- left / right voxel of the home row and the rows
+// below and above as one range each, every voxel pruned by its box distance against the home voxel's best.
+// (Pruning against `best` as it was after the home voxel scans a few more points than pruning range by range; the
+// minimum over a larger set of map points is the same.)
+__device__ __forceinline__ NearState nearest_home(const MapView &M, float qx, float qy, const NearPrep &P) {
+  NearState S;
   const int cx = P.cx, cy = P.cy;
-  const bool inside = P.inside;
-  const int *__restrict__ ps = M.pt_start;
+  S.cx = cx; S.cy = cy;
   const I4u h = P.h;
   float best = scan_bucket(M.pts, h.y, h.z, qx, qy, INFINITY);
   // distances from the query to the four walls of its voxel, shrunk by 1e-3 leaf so that a point
@@ -85,18 +98,17 @@ __device__ __forceinline__ float nearest_finish(const MapView &M, float qx, floa
   const float fx = qx - (float)(cx + M.min_bx) * L, fy = qy - (float)(cy + M.min_by) * L;
   float wl = fmaxf(fx - slack, 0.f), wr = fmaxf(L - fx - slack, 0.f);
   float wd = fmaxf(fy - slack, 0.f), wu = fmaxf(L - fy - slack, 0.f);
-  if (!inside) { wl = wr = wd = wu = 0.f; }            // clamped query: no pruning
+  if (!P.inside) { wl = wr = wd = wu = 0.f; }          // clamped query: no pruning
+  S.wl = wl; S.wr = wr; S.wd = wd; S.wu = wu;
+  S.best = best;
   const float wmin = fminf(fminf(wl, wr), fminf(wd, wu));
-  if (!(wmin * wmin < best)) return best;              // no other voxel can hold a closer point
-  // ring 1: left / right voxel of the home row and the rows below and above as one range each, every voxel pruned
-  // by its box distance against the home voxel's best.  The (up to four) ranges are walked as ONE sequence, kRingWide
-  // points in flight: four loops one after the other cost four chains of dependent loads per wave, because some
-  // lane of a wave nearly always needs each of them.  (Pruning against `best` as it was after the home voxel scans
-  // a few more points than pruning range by range; the minimum over a larger set of map points is the same.)
+  S.more = wmin * wmin < best;                         // else: no other voxel can hold a closer point
+  S.rn[0] = S.rn[1] = S.rn[2] = S.rn[3] = 0;
+  S.rs[0] = S.rs[1] = S.rs[2] = S.rs[3] = 0;
+  if (!S.more) return S;
   const bool has_l = cx > 0, has_r = cx + 1 < M.div_x;
-  int rs[4], rn[4];
-  rs[0] = h.x; rn[0] = (has_l && wl * wl < best) ? h.y - h.x : 0;
-  rs[1] = h.z; rn[1] = (has_r && wr * wr < best) ? h.w - h.z : 0;
+  S.rs[0] = h.x; S.rn[0] = (has_l && wl * wl < best) ? h.y - h.x : 0;
+  S.rs[1] = h.z; S.rn[1] = (has_r && wr * wr < best) ? h.w - h.z : 0;
 #pragma unroll
   for (int d = 0; d < 2; ++d) {
     const int yy = cy + (d ? 1 : -1);
@@ -105,25 +117,109 @@ __device__ __forceinline__ float nearest_finish(const MapView &M, float qx, floa
     const bool row_ok = yy >= 0 && yy < M.div_y && (by * by < best);
     const int sa = (has_l && wl * wl + by * by < best) ? o.x : o.y;
     const int sb = (has_r && wr * wr + by * by < best) ? o.w : o.z;
-    rs[2 + d] = sa; rn[2 + d] = row_ok ? sb - sa : 0;
+    S.rs[2 + d] = sa; S.rn[2 + d] = row_ok ? sb - sa : 0;
   }
-  {
-    constexpr int kRingWide = 8;
-    const int c1 = rn[0], c2 = c1 + rn[1], c3 = c2 + rn[2], total = c3 + rn[3];
-    // start of range j minus the number of points before it: index of sequence position t is off[j] + t
-    const int o0 = rs[0], o1 = rs[1] - c1, o2 = rs[2] - c2, o3 = rs[3] - c3;
-    for (int t0 = 0; t0 < total; t0 += kRingWide) {
-      float2 v[kRingWide];
+  return S;
+}
+
+// Phase 2, one lane on its own: the (up to four) ranges walked as ONE sequence, kRingWide points in flight: four loops
+// one after the other cost four chains of dependent loads.
+__device__ __forceinline__ float nearest_ring1_lane(const MapView &M, float qx, float qy, const NearState &S) {
+  float best = S.best;
+  constexpr int kRingWide = 8;
+  const int c1 = S.rn[0], c2 = c1 + S.rn[1], c3 = c2 + S.rn[2], total = c3 + S.rn[3];
+  // start of range j minus the number of points before it: index of sequence position t is off[j] + t
+  const int o0 = S.rs[0], o1 = S.rs[1] - c1, o2 = S.rs[2] - c2, o3 = S.rs[3] - c3;
+  for (int t0 = 0; t0 < total; t0 += kRingWide) {
+    float2 v[kRingWide];
 #pragma unroll
-      for (int u = 0; u < kRingWide; ++u) {
-        const int t = min(t0 + u, total - 1);            // past the end: the last point again (harmless for a minimum)
-        const int off = t < c1 ? o0 : (t < c2 ? o1 : (t < c3 ? o2 : o3));
-        v[u] = gld_f2_at(M.pts, (unsigned)(off + t) * 8u);
-      }
-#pragma unroll
-      for (int u = 0; u < kRingWide; ++u) best = fminf(best, sq_dist(qx, qy, v[u].x, v[u].y));
+    for (int u = 0; u < kRingWide; ++u) {
+      const int t = min(t0 + u, total - 1);            // past the end: the last point again (harmless for a minimum)
+      const int off = t < c1 ? o0 : (t < c2 ? o1 : (t < c3 ? o2 : o3));
+      v[u] = gld_f2_at(M.pts, (unsigned)(off + t) * 8u);
     }
+#pragma unroll
+    for (int u = 0; u < kRingWide; ++u) best = fminf(best, sq_dist(qx, qy, v[u].x, v[u].y));
   }
+  return best;
+}
+
+// Phase 2 for the 64 queries of a wave together.  Only a few lanes of a wave need ring 1 (9 % of the queries of a
+// well matched scan, two dozen points each), but some lane nearly always does, and then the whole wave walked that
+// lane's sequence: as much time as the home voxels for a fourteenth of the distance evaluations.  Here the lanes that
+// need it put their ranges into LDS and the (query, point) pairs of the whole wave are dealt out to all 64 lanes --
+// the same points, the same float32 expression, the minimum taken with an integer atomic (non-negative floats order
+// like their bit patterns), so the result is the one nearest_ring1_lane gives.
+#ifndef NDT_RING_JOINT_MAX
+#define NDT_RING_JOINT_MAX 12
+#endif
+constexpr int kRingJointMax = NDT_RING_JOINT_MAX;
+struct RingLds {                 // per wave
+  int start[64];                 // first item of the query with rank k (k-th lane that needs ring 1)
+  float qx[64], qy[64];
+  int o0[64], o1[64], o2[64], o3[64], c1[64], c2[64], c3[64];
+  unsigned res[64];
+};
+__device__ __forceinline__ float nearest_ring1_wave(const MapView &M, RingLds &R, float qx, float qy, const NearState &S) {
+  const int lane = threadIdx.x & 63;
+  const int T = S.rn[0] + S.rn[1] + S.rn[2] + S.rn[3];           // 0 for lanes without a query or with nothing to look at
+  const bool need = T > 0;
+  const unsigned long long mask = __ballot(need);
+  if (mask == 0ull) return S.best;                               // (wave-uniform)
+  const int K = __popcll(mask);
+  // many lanes with work of their own (poorly matched scans): each walks its own sequence, all lanes busy anyway
+  if (K > kRingJointMax) return need ? nearest_ring1_lane(M, qx, qy, S) : S.best;
+  const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+  int incl = T;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  const int W = __builtin_amdgcn_readlane(incl, 63);             // (query, point) pairs of the wave
+  if (need) {
+    const int c1 = S.rn[0], c2 = c1 + S.rn[1], c3 = c2 + S.rn[2];
+    R.start[rank] = incl - T;
+    R.qx[rank] = qx; R.qy[rank] = qy;
+    R.c1[rank] = c1; R.c2[rank] = c2; R.c3[rank] = c3;
+    R.o0[rank] = S.rs[0]; R.o1[rank] = S.rs[1] - c1; R.o2[rank] = S.rs[2] - c2; R.o3[rank] = S.rs[3] - c3;
+    R.res[rank] = __float_as_uint(S.best);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int steps = K > 1 ? 32 - __builtin_clz((unsigned)(K - 1)) : 0;      // binary search over the K starts
+  constexpr int kWide = 4;                                       // loads of a lane in flight
+  for (int i0 = 0; i0 < W; i0 += 64 * kWide) {
+    float2 v[kWide]; int q[kWide];
+#pragma unroll
+    for (int u = 0; u < kWide; ++u) {
+      const int i = min(i0 + u * 64 + lane, W - 1);              // past the end: the last pair again
+      int lo = 0, hi = K - 1;                                    // largest k with start[k] <= i
+      for (int s = 0; s < steps; ++s) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (R.start[mid] <= i) lo = mid; else hi = mid - 1;
+      }
+      q[u] = lo;
+      const int t = i - R.start[lo];
+      const int off = t < R.c1[lo] ? R.o0[lo] : (t < R.c2[lo] ? R.o1[lo] : (t < R.c3[lo] ? R.o2[lo] : R.o3[lo]));
+      v[u] = gld_f2_at(M.pts, (unsigned)(off + t) * 8u);
+    }
+#pragma unroll
+    for (int u = 0; u < kWide; ++u)
+      atomicMin(&R.res[q[u]], __float_as_uint(sq_dist(R.qx[q[u]], R.qy[q[u]], v[u].x, v[u].y)));
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return need ? __uint_as_float(R.res[rank]) : S.best;
+}
+
+// Phase 3: whole rings while the best distance exceeds the ring bound (rare: a query farther than a voxel from every
+// map point of its 3 x 3 neighbourhood).
+__device__ __forceinline__ float nearest_far(const MapView &M, float qx, float qy, const NearState &S, float best) {
+  if (!S.more) return best;
+  const int cx = S.cx, cy = S.cy;
+  const float wl = S.wl, wr = S.wr, wd = S.wd, wu = S.wu, L = M.leaf;
+  (void)wl; (void)wr;
+  const int *__restrict__ ps = M.pt_start;
   const double Ld = (double)L;
   const int rmax = M.div_x > M.div_y ? M.div_x : M.div_y;
   for (int r = 1; r <= rmax; ++r) {
@@ -155,7 +251,8 @@ __device__ __forceinline__ float nearest_finish(const MapView &M, float qx, floa
 }
 
 __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy) {
-  return nearest_finish(M, qx, qy, nearest_prep(M, qx, qy));
+  const NearState S = nearest_home(M, qx, qy, nearest_prep(M, qx, qy));
+  return nearest_far(M, qx, qy, S, S.more ? nearest_ring1_lane(M, qx, qy, S) : S.best);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -175,6 +272,7 @@ __global__ void __launch_bounds__(256, NDT_FIT_OCC)
 fitness_points_kernel(MapView M, const float *__restrict__ scans, const unsigned long long *__restrict__ offsets, int B,
                       int shared_scan, const float2 *__restrict__ sorted, const ndt_result *__restrict__ results,
                       float *__restrict__ fit) {
+  __shared__ RingLds ring[256 / 64];
   for (int b = blockIdx.y; b < B; b += gridDim.y) {
     const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
     const unsigned long long o1 = shared_scan ? offsets[1] : offsets[b + 1];
@@ -185,11 +283,19 @@ fitness_points_kernel(MapView M, const float *__restrict__ scans, const unsigned
     const size_t slot = shared_scan ? (size_t)b * (size_t)n : (size_t)o0;
     const float2 *pts = use_sorted ? sorted + slot : reinterpret_cast<const float2 *>(scans) + o0;
     float *out = fit + slot;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-      const float2 pt = pts[i];
+    // whole waves stay together (the ring-1 phase is a wave's joint work): lanes past the end carry no query
+    for (int i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
+      const int i = i0 + (int)(threadIdx.x & 63u);
+      const float2 pt = pts[min(i, n - 1)];
       float qx, qy;
       tf_apply_t<SSE>(T, pt.x, pt.y, qx, qy);
-      out[i] = finite2(qx, qy) ? nearest_sq(M, qx, qy) : INFINITY;
+      const bool live = i < n && finite2(qx, qy);
+      if (!live) { qx = 0.f; qy = 0.f; }                         // (any address inside the grid; the result is dropped)
+      NearState S = nearest_home(M, qx, qy, nearest_prep(M, qx, qy));
+      if (!live) { S.more = false; S.rn[0] = S.rn[1] = S.rn[2] = S.rn[3] = 0; }
+      float best = nearest_ring1_wave(M, ring[threadIdx.x >> 6], qx, qy, S);
+      best = nearest_far(M, qx, qy, S, best);
+      if (i < n) out[i] = live ? best : INFINITY;
     }
   }
 }

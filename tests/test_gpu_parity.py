@@ -120,6 +120,41 @@ def test_fitness_matches_oracle(gpu, oracle, c1_world):
         assert gm.fitness_at(scan, c, s, tx, ty) == pytest.approx(om.fitness(scan, c, s, tx, ty), rel=1e-13)
 
 
+def test_batch_fitness_ring_phase_matches_the_single_query_search(gpu, oracle):
+    """The fitness kernels of a batch deal the ring-1 work of a wave out to all its lanes (ndt_fitness.hip.h,
+    nearest_ring1_wave) when few lanes need it and let every lane walk its own otherwise; `ndt_fitness_at` runs the
+    plain per-query search.  Same points, same float32 expression: equal distances, equal sums.  Cases: well matched
+    10k-point scans, a scan of ragged length with NaN points, and poses 0.4 .. 3 m off (every lane needs rings;
+    max_iter = 0 keeps the match at its first pose)."""
+    capi, ctx = gpu
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C2"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    scans, off, truths, inits = sf.batch(0, 6)
+    parts, lens = [], []
+    for b in range(6):
+        sc = scans[int(off[b]):int(off[b + 1])].copy()
+        if b == 1:
+            sc = sc[:9973]
+            sc[[5, 64, 4097, 9972]] = np.nan
+        parts.append(sc); lens.append(len(sc))
+    scans = np.concatenate(parts)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    for kw, shift in ((dict(), 0.0), (dict(max_iter=0), 0.4), (dict(max_iter=0), 3.0)):
+        prm = capi.default_params(resolution=cfg["resolution"], **kw)
+        gm = capi.Map(ctx, m, prm)
+        om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"], **kw))
+        start = inits + np.array([shift, -0.5 * shift, 0.02 * shift])
+        res = gm.align_batch(scans, off, start)
+        for b in range(6):
+            sc = scans[int(off[b]):int(off[b + 1])]
+            r = res[b]
+            single = gm.fitness_at(sc, r["T00"], r["T10"], r["T03"], r["T13"])
+            assert r["fitness"] == pytest.approx(single, rel=1e-13), (kw, shift, b)
+            assert r["fitness"] == pytest.approx(om.fitness(sc, r["T00"], r["T10"], r["T03"], r["T13"]), rel=1e-13)
+
+
 # ------------------------------------------------------------------------------------------ a3-a9
 def test_c1_matches_oracle_with_same_step_sequence(gpu, oracle, c1_world):
     """BASELINE.json configs[0]: 360-pt scan vs 5k-pt map, launch-file parameters."""
