@@ -115,10 +115,12 @@ scan_tile_sums_kernel(const int *__restrict__ in, size_t n, int *__restrict__ ti
 }
 
 __global__ void __launch_bounds__(1024)
-scan_tile_offsets_kernel(int *__restrict__ tile_sum, int ntiles, int *__restrict__ total) {
-  // single workgroup: exclusive scan of the tile sums, in place
+scan_tile_offsets_kernel(int *__restrict__ tile_sum, int ntiles, int *__restrict__ total, int *__restrict__ counters) {
+  // single workgroup: exclusive scan of the tile sums, in place (and the build's three small counters cleared for the
+  // kernels behind this one)
   __shared__ int sh[1024];
   __shared__ int carry;
+  if (threadIdx.x < 4) counters[threadIdx.x] = 0;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   for (int base = 0; base < ntiles; base += 1024) {
@@ -179,12 +181,16 @@ scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ 
     for (int k = 0; k < kScanPer; ++k)
       if ((bigmask >> k) & 1u) { if (q0 < big_cap) big[q0] = (int)(base + k); ++q0; }
   }
-  if (blockIdx.x == 0 && threadIdx.x < 4) out[n + threadIdx.x] = *total;   // out[n], + 3 readable copies
+  if (blockIdx.x == 0 && threadIdx.x < 4) {
+    out[n + threadIdx.x] = *total;               // out[n], + 3 readable copies
+    out[(int)threadIdx.x - 4] = 0;               // the four readable ints in front of out[0] (ndt_fitness.hip.h)
+  }
 }
 
 __global__ void __launch_bounds__(256)
 map_scatter_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims G,
-                   const int *__restrict__ start, int *__restrict__ fill, int *__restrict__ perm) {
+                   const int *__restrict__ start, int *__restrict__ count /* in: points per voxel; out: zero */,
+                   int *__restrict__ perm) {
   const int lane = threadIdx.x & 63;
   const size_t nround = (n + 63) / 64 * 64;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nround; i += (size_t)gridDim.x * blockDim.x) {
@@ -192,7 +198,7 @@ map_scatter_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDi
     int head, len;
     wave_runs(v, lane, head, len);
     int base = 0;
-    if (head == lane && v >= 0) base = start[v] + atomicAdd(&fill[v], len);   // one slot range per run
+    if (head == lane && v >= 0) base = start[v] + atomicSub(&count[v], len) - len;   // one slot range per run, from the bucket's end
     base = __shfl(base, head);
     if (v >= 0) perm[base + (lane - head)] = (int)i;                          // cloud order kept inside a run
   }

@@ -99,8 +99,9 @@ struct ndt_map {
   MapView view;
   size_t n = 0, ng = 0, npad = 0;
   // device buffers (grow-only across rebuilds)
-  int *count = nullptr, *start = nullptr, *fill = nullptr, *tile = nullptr, *npts_grid = nullptr;
-  size_t count_cap = 0, start_cap = 0, fill_cap = 0, tile_cap = 0, npts_cap = 0;
+  int *count = nullptr, *start = nullptr, *tile = nullptr, *npts_grid = nullptr;
+  size_t count_cap = 0, start_cap = 0, tile_cap = 0, npts_cap = 0;
+  bool count_clean = false;                   // count[0 .. count_cap) is all zero (a complete build leaves it so: the scatter takes back what the count added)
   int *perm = nullptr, *perm_sorted = nullptr; float2 *pts = nullptr;
   size_t perm_cap = 0, perm_sorted_cap = 0, pts_cap = 0;
   float2 *cent = nullptr; double *rec = nullptr; size_t cent_cap = 0, rec_cap = 0;
@@ -409,7 +410,7 @@ int ndt_map_destroy(ndt_map *m) {
   if (!m) return NDT_E_ARG;
   hipError_t e = hipSetDevice(m->ctx->device);
   e = hipStreamSynchronize(m->ctx->stream);
-  void *bufs[] = {m->occ, m->big, m->count, m->start, m->fill, m->tile, m->npts_grid, m->perm, m->perm_sorted, m->pts,
+  void *bufs[] = {m->occ, m->big, m->count, m->start, m->tile, m->npts_grid, m->perm, m->perm_sorted, m->pts,
                   m->cent, m->rec, m->bounds, m->counters, m->total, m->d_xy_stage};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
@@ -430,9 +431,10 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   {
     int rc;
     const size_t ntiles_ = (ng + kScanTile - 1) / kScanTile;
+    const size_t count_cap_before = m->count_cap;
     if ((rc = ensure_t(ctx, &m->count, &m->count_cap, ng + 1))) return rc;
+    if (m->count_cap != count_cap_before) m->count_clean = false;      // a new allocation
     if ((rc = ensure_t(ctx, &m->start, &m->start_cap, ng + 1 + 8))) return rc;   // 4 readable ints before, 3 after (nearest_sq)
-    if ((rc = ensure_t(ctx, &m->fill, &m->fill_cap, ng + 1))) return rc;
     if ((rc = ensure_t(ctx, &m->npts_grid, &m->npts_cap, ng + 1))) return rc;
     if ((rc = ensure_t(ctx, &m->tile, &m->tile_cap, ntiles_ + 1))) return rc;
     if ((rc = ensure_t(ctx, &m->perm, &m->perm_cap, n))) return rc;
@@ -443,9 +445,11 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
     if ((rc = ensure_t(ctx, &m->cent, &m->cent_cap, npad))) return rc;
     if ((rc = ensure_t(ctx, &m->rec, &m->rec_cap, npad * 8))) return rc;
   }
-  HIP_TRY(ctx, hipMemsetAsync(m->count, 0, (ng + 1) * sizeof(int), st));
-  HIP_TRY(ctx, hipMemsetAsync(m->fill, 0, (ng + 1) * sizeof(int), st));
-  HIP_TRY(ctx, hipMemsetAsync(m->counters, 0, 4 * sizeof(int), st));
+  // No clearing in the steady state (every memset is a kernel of its own between the build's kernels): the per-voxel
+  // counters are zero again after a complete build (map_scatter_kernel takes back what map_count_kernel added), the
+  // three small counters are cleared by scan_tile_offsets_kernel, the readable ints in front of `start` by scan_apply_kernel.
+  if (!m->count_clean) HIP_TRY(ctx, hipMemsetAsync(m->count, 0, m->count_cap * sizeof(int), st));
+  m->count_clean = false;
   // (records of voxels outside the search set are never read: no clearing of m->rec)
   fill_f2_kernel<<<grid_for(npad, 256), 256, 0, st>>>(m->cent, npad, INFINITY);
 
@@ -453,12 +457,13 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   map_count_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, m->count);
   const int ntiles = (int)((ng + kScanTile - 1) / kScanTile);
   scan_tile_sums_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile);
-  scan_tile_offsets_kernel<<<1, 1024, 0, st>>>(m->tile, ntiles, m->total);
-  HIP_TRY(ctx, hipMemsetAsync(m->start, 0, 4 * sizeof(int), st));
+  scan_tile_offsets_kernel<<<1, 1024, 0, st>>>(m->tile, ntiles, m->total, m->counters);
   int *const start = m->start + 4;
   const int big_cap = (int)(n / kBigVoxel + 1);
   scan_apply_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, start, m->total, m->big, m->counters + 2, big_cap);
-  map_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, start, m->fill, m->perm);
+  map_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, start, m->count, m->perm);
+  HIP_TRY(ctx, hipGetLastError());
+  m->count_clean = true;
   map_order_small_kernel<<<(unsigned)((ng + kOrderVoxPerBlock - 1) / kOrderVoxPerBlock), 256, 0, st>>>(start, ng, m->perm, m->perm_sorted);
   map_order_big_kernel<<<kBigBlocks, 256, 0, st>>>(start, m->big, m->counters + 2, big_cap, m->perm, m->perm_sorted);
 
