@@ -22,9 +22,12 @@ __host__ __device__ inline float ord2f(unsigned u) {
   return f;
 }
 
-// getMinMax3D: bounds[0..3] = ord(min x), ord(min y), ord(max x), ord(max y)
+// getMinMax3D: out[0..3] = ord(min x), ord(min y), ord(max x), ord(max y).  bounds[0..3] is the running result and
+// bounds[8] counts the workgroups that are done; the last one hands the result over and puts both back to their
+// start values ({~0, ~0, 0, 0}, 0 -- set once when the map is created): no initialising copy in front of every build.
 __global__ void __launch_bounds__(256)
-map_minmax_kernel(const float *__restrict__ xy, size_t stride, size_t n, unsigned *__restrict__ bounds) {
+map_minmax_kernel(const float *__restrict__ xy, size_t stride, size_t n, unsigned *__restrict__ bounds,
+                  unsigned *__restrict__ out) {
   __shared__ float sh[4][4];
   float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
   const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -55,6 +58,13 @@ map_minmax_kernel(const float *__restrict__ xy, size_t stride, size_t n, unsigne
     if (mnx <= mxx) {     // one atomic set per workgroup
       atomicMin(&bounds[0], f2ord(mnx)); atomicMin(&bounds[1], f2ord(mny));
       atomicMax(&bounds[2], f2ord(mxx)); atomicMax(&bounds[3], f2ord(mxy));
+    }
+    __threadfence();
+    if (atomicAdd(&bounds[8], 1u) == gridDim.x - 1u) {      // the last workgroup: every other one's atomics are in
+      __threadfence();
+      out[0] = atomicExch(&bounds[0], 0xffffffffu); out[1] = atomicExch(&bounds[1], 0xffffffffu);
+      out[2] = atomicExch(&bounds[2], 0u);          out[3] = atomicExch(&bounds[3], 0u);
+      atomicExch(&bounds[8], 0u);
     }
   }
 }
@@ -101,8 +111,9 @@ constexpr int kScanBlock = 256, kScanPer = 8, kScanTile = kScanBlock * kScanPer;
 constexpr int kBigVoxel = 16;        // voxels with more points are handled by a whole wave (order, statistics)
 
 __global__ void __launch_bounds__(kScanBlock)
-scan_tile_sums_kernel(const int *__restrict__ in, size_t n, int *__restrict__ tile_sum) {
+scan_tile_sums_kernel(const int *__restrict__ in, size_t n, int *__restrict__ tile_sum, int *__restrict__ counters) {
   __shared__ int sh[kScanBlock / 64];
+  if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0;     // the build's small counters, for the kernels behind this one
   size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPer;
   int s = 0;
 #pragma unroll
@@ -114,40 +125,24 @@ scan_tile_sums_kernel(const int *__restrict__ in, size_t n, int *__restrict__ ti
   if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kScanBlock / 64; ++w) t += sh[w]; tile_sum[blockIdx.x] = t; }
 }
 
-__global__ void __launch_bounds__(1024)
-scan_tile_offsets_kernel(int *__restrict__ tile_sum, int ntiles, int *__restrict__ total, int *__restrict__ counters) {
-  // single workgroup: exclusive scan of the tile sums, in place (and the build's three small counters cleared for the
-  // kernels behind this one)
-  __shared__ int sh[1024];
-  __shared__ int carry;
-  if (threadIdx.x < 4) counters[threadIdx.x] = 0;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (int base = 0; base < ntiles; base += 1024) {
-    int i = base + threadIdx.x;
-    int v = i < ntiles ? tile_sum[i] : 0;
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-      __syncthreads();
-      sh[threadIdx.x] += t;
-      __syncthreads();
-    }
-    int incl = sh[threadIdx.x];
-    if (i < ntiles) tile_sum[i] = carry + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry += incl;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *total = carry;
-}
-
 __global__ void __launch_bounds__(kScanBlock)
-scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ tile_off,
-                  int *__restrict__ out /* n + 1 */, const int *__restrict__ total,
+scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ tile_sum, int ntiles,
+                  int *__restrict__ out /* n + 1 */,
                   int *__restrict__ big /* voxels with more than kBigVoxel points */, int *__restrict__ nbig, int big_cap) {
   __shared__ int sh[kScanBlock];
+  __shared__ int tile_base, grand_total;
+  // offset of this tile = sum of the tile sums in front of it (a few hundred values: every workgroup adds them up
+  // itself -- a scan kernel of one workgroup between two kernels cost a launch latency for 4 us of work)
+  {
+    int before = 0, all = 0;
+    for (int t = threadIdx.x; t < ntiles; t += kScanBlock) { const int v = tile_sum[t]; all += v; if (t < (int)blockIdx.x) before += v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { before += __shfl_down(before, o); all += __shfl_down(all, o); }
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = before; sh[4 + (threadIdx.x >> 6)] = all; }
+    __syncthreads();
+    if (threadIdx.x == 0) { tile_base = sh[0] + sh[1] + sh[2] + sh[3]; grand_total = sh[4] + sh[5] + sh[6] + sh[7]; }
+    __syncthreads();
+  }
   size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPer;
   int v[kScanPer]; int s = 0;
 #pragma unroll
@@ -160,7 +155,7 @@ scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ 
     sh[threadIdx.x] += t;
     __syncthreads();
   }
-  int run = tile_off[blockIdx.x] + sh[threadIdx.x] - s;
+  int run = tile_base + sh[threadIdx.x] - s;
   unsigned bigmask = 0;
 #pragma unroll
   for (int k = 0; k < kScanPer; ++k) {
@@ -182,7 +177,7 @@ scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ 
       if ((bigmask >> k) & 1u) { if (q0 < big_cap) big[q0] = (int)(base + k); ++q0; }
   }
   if (blockIdx.x == 0 && threadIdx.x < 4) {
-    out[n + threadIdx.x] = *total;               // out[n], + 3 readable copies
+    out[n + threadIdx.x] = grand_total;          // out[n], + 3 readable copies
     out[(int)threadIdx.x - 4] = 0;               // the four readable ints in front of out[0] (ndt_fitness.hip.h)
   }
 }
@@ -209,12 +204,11 @@ map_scatter_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDi
 // points: eight lanes per voxel (one wave per voxel spent its time launching waves, 70 % of the
 // voxels being empty); the others, listed by scan_apply_kernel: one wave per voxel.
 constexpr int kOrderVoxPerBlock = 256 / 8 * 4;     // 32 lane groups, 4 voxels each
-__global__ void __launch_bounds__(256)
-map_order_small_kernel(const int *__restrict__ start, size_t ng, const int *__restrict__ perm,
-                       int *__restrict__ perm_sorted) {
+__device__ __forceinline__ void order_small_voxels(unsigned block, const int *__restrict__ start, size_t ng,
+                                                   const int *__restrict__ perm, int *__restrict__ perm_sorted) {
   const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
   for (int r = 0; r < 4; ++r) {
-    const size_t g = (size_t)blockIdx.x * kOrderVoxPerBlock + (size_t)r * 32 + grp;
+    const size_t g = (size_t)block * kOrderVoxPerBlock + (size_t)r * 32 + grp;
     if (g >= ng) return;
     const int s0 = start[g], n = start[g + 1] - s0;
     if (n > kBigVoxel) continue;
@@ -228,13 +222,17 @@ map_order_small_kernel(const int *__restrict__ start, size_t ng, const int *__re
 }
 
 constexpr int kBigWavesPerBlock = 4, kBigBlocks = 1024, kBigStage = 512;   // LDS staging: point numbers per wave
+// One launch for both kinds (they do not depend on each other): workgroups [0, small_blocks) take the small voxels,
+// the kBigBlocks behind them the listed big ones.
 __global__ void __launch_bounds__(256)
-map_order_big_kernel(const int *__restrict__ start, const int *__restrict__ big, const int *__restrict__ nbig,
-                     int big_cap, const int *__restrict__ perm, int *__restrict__ perm_sorted) {
+map_order_kernel(const int *__restrict__ start, size_t ng, unsigned small_blocks, const int *__restrict__ big,
+                 const int *__restrict__ nbig, int big_cap, const int *__restrict__ perm, int *__restrict__ perm_sorted) {
   __shared__ int stage[kBigWavesPerBlock][kBigStage];
+  if (blockIdx.x < small_blocks) { order_small_voxels(blockIdx.x, start, ng, perm, perm_sorted); return; }
+  const unsigned bblock = blockIdx.x - small_blocks, bblocks = gridDim.x - small_blocks;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int count = min(*nbig, big_cap);
-  for (int q = blockIdx.x * kBigWavesPerBlock + wv; q < count; q += gridDim.x * kBigWavesPerBlock) {
+  for (int q = bblock * kBigWavesPerBlock + wv; q < count; q += bblocks * kBigWavesPerBlock) {
     const int g = big[q];
     const int s0 = start[g], n = start[g + 1] - s0;
     const bool staged = n <= kBigStage;

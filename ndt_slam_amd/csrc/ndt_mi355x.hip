@@ -58,6 +58,8 @@ struct ndt_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the last match launch
   hipEvent_t evm0 = nullptr, evm1 = nullptr; // around the last map build
   hipEvent_t evb = nullptr;                  // bounding box of the map build read back
+  hipStream_t side = nullptr;                // map build: bounding box + centroid fill beside the bucketing chain
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool map_ms_pending = false;
   unsigned *h_bounds = nullptr;              // pinned: bounding box read-back of the map build
   std::string err;
@@ -306,6 +308,13 @@ static int ctx_init(ndt_ctx *c, int device) {
   HIP_TRY(c, hipEventCreate(&c->evm0));
   HIP_TRY(c, hipEventCreate(&c->evm1));
   HIP_TRY(c, hipEventCreateWithFlags(&c->evb, hipEventDisableTiming));
+  {
+    int lo = 0, hi = 0;
+    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_TRY(c, hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, hi));
+  }
+  HIP_TRY(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  HIP_TRY(c, hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreateWithFlags(&c->ev_mm, hipEventDisableTiming));
   HIP_TRY(c, hipEventCreateWithFlags(&c->ev_scratch, hipEventDisableTiming));
   for (hipEvent_t &e : c->ev_ring) HIP_TRY(c, hipEventCreate(&e));
@@ -357,6 +366,9 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->evm0) e = hipEventDestroy(c->evm0);
   if (c->evm1) e = hipEventDestroy(c->evm1);
   if (c->evb) e = hipEventDestroy(c->evb);
+  if (c->side) { e = hipStreamSynchronize(c->side); e = hipStreamDestroy(c->side); }
+  if (c->ev_fork) e = hipEventDestroy(c->ev_fork);
+  if (c->ev_join) e = hipEventDestroy(c->ev_join);
   if (c->h_bounds) e = hipHostFree(c->h_bounds);
   if (c->ev_mm) e = hipEventDestroy(c->ev_mm);
   if (c->ev_scratch) e = hipEventDestroy(c->ev_scratch);
@@ -451,21 +463,23 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   if (!m->count_clean) HIP_TRY(ctx, hipMemsetAsync(m->count, 0, m->count_cap * sizeof(int), st));
   m->count_clean = false;
   // (records of voxels outside the search set are never read: no clearing of m->rec)
-  fill_f2_kernel<<<grid_for(npad, 256), 256, 0, st>>>(m->cent, npad, INFINITY);
+  // (the centroid grid is reset on the side stream, beside the bucketing chain; joined in front of the statistics)
+  fill_f2_kernel<<<grid_for(npad, 256), 256, 0, ctx->side>>>(m->cent, npad, INFINITY);
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
 
   // 3. bucket the points by voxel, cloud order kept inside a bucket
   map_count_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, m->count);
   const int ntiles = (int)((ng + kScanTile - 1) / kScanTile);
-  scan_tile_sums_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile);
-  scan_tile_offsets_kernel<<<1, 1024, 0, st>>>(m->tile, ntiles, m->total, m->counters);
+  scan_tile_sums_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, m->counters);
   int *const start = m->start + 4;
   const int big_cap = (int)(n / kBigVoxel + 1);
-  scan_apply_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, start, m->total, m->big, m->counters + 2, big_cap);
+  scan_apply_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, ntiles, start, m->big, m->counters + 2, big_cap);
   map_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, start, m->count, m->perm);
   HIP_TRY(ctx, hipGetLastError());
   m->count_clean = true;
-  map_order_small_kernel<<<(unsigned)((ng + kOrderVoxPerBlock - 1) / kOrderVoxPerBlock), 256, 0, st>>>(start, ng, m->perm, m->perm_sorted);
-  map_order_big_kernel<<<kBigBlocks, 256, 0, st>>>(start, m->big, m->counters + 2, big_cap, m->perm, m->perm_sorted);
+  const unsigned small_blocks = (unsigned)((ng + kOrderVoxPerBlock - 1) / kOrderVoxPerBlock);
+  map_order_kernel<<<small_blocks + kBigBlocks, 256, 0, st>>>(start, ng, small_blocks, m->big, m->counters + 2, big_cap, m->perm, m->perm_sorted);
+  HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
 
   // 4. per-voxel statistics -> centroid grid + cell records + bucketed raw points
   LeafParams L;
@@ -498,12 +512,14 @@ static int map_build_impl(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, s
   // during that round trip, the rest of the build is queued at once with the grid of the previous
   // build of this map (a SLAM local map keeps its voxel bounding box for many scans) and redone
   // only if the read-back disagrees.
-  unsigned init_b[4] = {0xffffffffu, 0xffffffffu, 0u, 0u};
-  HIP_TRY(ctx, hipMemcpyAsync(m->bounds, init_b, sizeof(init_b), hipMemcpyHostToDevice, st));
-  map_minmax_kernel<<<grid_for(n, 256 * 32, 128), 256, 0, st>>>(xy, stride, n, m->bounds);
+  // The bounding box (and the reset of the centroid grid, queue_build) run on a side stream beside the bucketing
+  // chain -- a dozen dependent kernels whose launch latencies add up -- and are joined in front of the statistics.
+  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  map_minmax_kernel<<<grid_for(n, 256 * 32, 128), 256, 0, ctx->side>>>(xy, stride, n, m->bounds, m->bounds + 4);
   unsigned *hb = ctx->h_bounds;                // pinned
-  HIP_TRY(ctx, hipMemcpyAsync(hb, m->bounds, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-  HIP_TRY(ctx, hipEventRecord(ctx->evb, st));
+  HIP_TRY(ctx, hipMemcpyAsync(hb, m->bounds + 4, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side));
+  HIP_TRY(ctx, hipEventRecord(ctx->evb, ctx->side));
   const float inv_leaf = 1.0f / prm->resolution;
   bool queued = false;
   if (m->have_grid && m->grid.inv_leaf == inv_leaf) {
@@ -547,7 +563,9 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
     m = new (std::nothrow) ndt_map();
     if (!m) return NDT_E_NOMEM;
     m->ctx = ctx;
-    hipError_t e = hipMalloc(&m->bounds, 4 * sizeof(unsigned));
+    hipError_t e = hipMalloc(&m->bounds, 16 * sizeof(unsigned));
+    const unsigned init_b[16] = {0xffffffffu, 0xffffffffu, 0u, 0u};     // running bounding box, result, done-counter (map_minmax_kernel)
+    if (e == hipSuccess) e = hipMemcpy(m->bounds, init_b, sizeof(init_b), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&m->counters, 4 * sizeof(int));
     if (e == hipSuccess) e = hipMalloc(&m->total, sizeof(int));
     if (e != hipSuccess) { ndt_map_destroy(m); return fail(ctx, NDT_E_HIP, std::string("ndt_map_build: hipMalloc: ") + hipGetErrorString(e)); }
