@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="matches per GPU and step (default 256 for C3, 512 for C5)")
     ap.add_argument("--inflight", type=int, default=1, choices=[1, 2, 3, 4], help="match launches in flight (k: k contexts / streams in turn, k + 1 map buffers)")
     ap.add_argument("--workgroups", type=int, default=0, help="workgroups per match launch (0 = one per CU); fewer leave CUs to the map build's stream")
-    ap.add_argument("--max-helpers", type=int, default=-1, help="helper workgroups per unfinished scan (default: the library's 15); fewer free CUs earlier for the next launch")
+    ap.add_argument("--max-helpers", type=int, default=-1, help="helper workgroups per unfinished scan (default: the library's 8); fewer free CUs earlier for whatever is queued behind the launch")
     ap.add_argument("--time-builds", action="store_true", help="extra events around the map build and around the whole launch inside the step loop (launch_interval_ms, map_build_in_step_ms)")
     ap.add_argument("--no-scatter", action="store_true", help="N > 1: every rank generates its own shard instead of receiving it from rank 0")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -239,6 +239,8 @@ def main():
     tp_off = capi.RESULT_DTYPE.fields["trans_prob"][1]
     seed_index = (rank + SEED_SHARDS * torch.arange(B, dtype=torch.int64)).to(comm_dev) if c5 else None
 
+    open_build = []                                       # the map whose rebuild_end is still owed (one per context)
+
     def step(i):
         gm = gmaps[i % nbuf]
         st, cx = streams[i % args.inflight], mctx[i % args.inflight]
@@ -248,7 +250,14 @@ def main():
             bstream.wait_event(ev_a[2 * (i - nbuf) + 1])
         if args.time_builds:
             ev_m[2 * i].record(bstream)
-        gm.rebuild(dev_ptr=d_map.data_ptr(), n=len(map_xy), stride=8)
+        # two-phase rebuild (ndt_map_rebuild_begin / _end): the build is queued with the voxel grid of the map's last
+        # build and the host goes on -- it collects the verdict on that grid one step later, so the GPU never waits for
+        # the host's wake-up from the bounding-box read-back (a plain rebuild blocks right here in every step)
+        if open_build:
+            stale = open_build.pop().rebuild_end()
+            assert not stale, "the map's bounding box moved: the matches queued on the speculative grid would have to be repeated"
+        gm.rebuild_begin(d_map.data_ptr(), len(map_xy), 8)
+        open_build.append(gm)
         ev_m[2 * i + 1].record(bstream)
         # a3-a9 for the whole batch: one launch, after this step's build (the library makes the match stream wait
         # for the build of the map it is given: no second wait here -- every wait is a packet between two kernels)
@@ -280,6 +289,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.warmup, nst):
         step(i)
+    if open_build:                                         # the verdict on the last step's grid belongs to the timed region
+        assert not open_build.pop().rebuild_end()
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:

@@ -123,7 +123,7 @@ int ndt_ctx_destroy(ndt_ctx *ctx);               /* destroy the context's maps f
 const char *ndt_last_error(const ndt_ctx *ctx);   /* ctx may be NULL: last global error */
 void *ndt_ctx_stream(ndt_ctx *ctx);               /* hipStream_t the context works on   */
 /* Tuning of the match launch (defaults are right for whole-GPU batches):
- *   NDT_OPT_MAX_HELPERS  0..15  workgroups that may join the passes of one unfinished scan; 0 = no work sharing
+ *   NDT_OPT_MAX_HELPERS  0..15  workgroups that may join the passes of one unfinished scan (default 8); 0 = no work sharing
  *   NDT_OPT_WORKGROUPS   0..#CU workgroups per match launch (0 = one per CU); a smaller value leaves CUs to
  *                               other streams
  * Results never depend on either (unit totals are summed in unit order whoever computed them). */
@@ -143,6 +143,17 @@ int ndt_map_build(ndt_ctx *ctx, const float *xy_host, size_t n, size_t stride_by
                   const ndt_params *prm, ndt_map **map);
 int ndt_map_build_dev(ndt_ctx *ctx, const float *xy_dev, size_t n, size_t stride_bytes,
                       const ndt_params *prm, ndt_map **map);
+/* The same rebuild in two halves for a pipeline that must not wait on the host: _begin queues the
+ * bounding box of the new cloud and, ahead of its read-back, the whole build with the voxel grid of the map's previous
+ * build, and returns; launches queued behind it see that build.  _end waits for the bounding box: NDT_OK if the grid
+ * was the right one (a SLAM local map keeps its voxel bounding box for many scans, src/PointCloudMap.cpp:119-131),
+ * NDT_REBUILT if it was not -- the build has been queued again, and whatever was queued between _begin and _end ran on
+ * a stale grid and has to be queued again by the caller.  One _begin may be open per context.  The map must have been
+ * built before at the same resolution. */
+#define NDT_REBUILT 1
+int ndt_map_rebuild_begin(ndt_ctx *ctx, const float *xy_dev, size_t n, size_t stride_bytes,
+                          const ndt_params *prm, ndt_map *map);
+int ndt_map_rebuild_end(ndt_ctx *ctx, ndt_map *map);
 int ndt_map_destroy(ndt_map *map);
 int ndt_map_info_get(const ndt_map *map, ndt_map_info *out);
 /* Cell table in ascending voxel-index order, arrays sized n_cells (parity tests). */

@@ -55,7 +55,7 @@ OPT_MAX_HELPERS, OPT_WORKGROUPS = 1, 2                                # ndt_ctx_
 EXPORTS = [
     "ndt_default_params", "ndt_params_pcl110", "ndt_params_pcl18", "ndt_params_pcl_new", "ndt_ctx_create", "ndt_ctx_destroy", "ndt_last_error", "ndt_ctx_stream",
     "ndt_ctx_set_stream", "ndt_ctx_set_option",
-    "ndt_map_build", "ndt_map_build_dev", "ndt_map_destroy", "ndt_map_info_get", "ndt_map_export",
+    "ndt_map_build", "ndt_map_build_dev", "ndt_map_rebuild_begin", "ndt_map_rebuild_end", "ndt_map_destroy", "ndt_map_info_get", "ndt_map_export",
     "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_trace", "ndt_eval_at",
     "ndt_fitness_at", "ndt_last_timing", "ndt_kernel_timing", "ndt_prefilter", "ndt_prefilter_batch_dev",
     "ndt_fuse_default_params", "ndt_predict_batch_dev", "ndt_fuse_batch_dev",
@@ -86,6 +86,8 @@ def lib():
     L.ndt_ctx_set_option.argtypes = [vp, i, C.c_longlong]
     L.ndt_map_build.argtypes = [vp, vp, sz, sz, C.POINTER(Params), C.POINTER(vp)]
     L.ndt_map_build_dev.argtypes = [vp, vp, sz, sz, C.POINTER(Params), C.POINTER(vp)]
+    L.ndt_map_rebuild_begin.argtypes = [vp, vp, sz, sz, C.POINTER(Params), vp]
+    L.ndt_map_rebuild_end.argtypes = [vp, vp]
     L.ndt_map_destroy.argtypes = [vp]
     L.ndt_map_info_get.argtypes = [vp, C.POINTER(MapInfo)]
     L.ndt_map_export.argtypes = [vp, vp, vp, vp, vp, vp]
@@ -287,6 +289,19 @@ class Map:
             xy = _f32c(xy)
             rc = lib().ndt_map_build(self.ctx.h, xy.ctypes.data, len(xy), 8, C.byref(self.params), C.byref(self.h))
         self.ctx.check(rc, "ndt_map_build")
+
+    def rebuild_begin(self, dev_ptr, n, stride=8):
+        """Queue the rebuild with the voxel grid of the previous build and return (no host wait); see rebuild_end."""
+        self.ctx.check(lib().ndt_map_rebuild_begin(self.ctx.h, dev_ptr, n, stride, C.byref(self.params), self.h),
+                       "ndt_map_rebuild_begin")
+
+    def rebuild_end(self):
+        """True if the cloud's bounding box had moved: the build was queued again and launches queued since
+        rebuild_begin used a stale grid."""
+        rc = lib().ndt_map_rebuild_end(self.ctx.h, self.h)
+        if rc < 0:
+            self.ctx.check(rc, "ndt_map_rebuild_end")
+        return rc == 1
 
     def info(self):
         i = MapInfo()

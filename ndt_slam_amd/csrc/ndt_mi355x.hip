@@ -58,6 +58,7 @@ struct ndt_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;   // around the last match launch
   hipEvent_t evm0 = nullptr, evm1 = nullptr; // around the last map build
   hipEvent_t evb = nullptr;                  // bounding box of the map build read back
+  ndt_map *pending_map = nullptr;            // ndt_map_rebuild_begin without its _end (one at a time: the read-back buffer is the context's)
   hipStream_t side = nullptr;                // map build: bounding box + centroid fill beside the bucketing chain
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool map_ms_pending = false;
@@ -110,6 +111,8 @@ struct ndt_map {
   unsigned *bounds = nullptr; int *counters = nullptr; int *total = nullptr;   // counters: n_cells, n_valid, n_big
   int *big = nullptr; size_t big_cap = 0;
   unsigned *occ = nullptr; size_t occ_cap = 0;
+  bool pending = false, pend_queued = false;  // between ndt_map_rebuild_begin and _end
+  const float *pend_xy = nullptr; size_t pend_stride = 0;
   GridDims grid; bool have_grid = false;      // voxel grid of the last build (queued ahead of the next one's bounding box)
   void *d_xy_stage = nullptr; size_t d_xy_cap = 0;
 };
@@ -323,7 +326,7 @@ static int ctx_init(ndt_ctx *c, int device) {
   hipDeviceProp_t prop;
   HIP_TRY(c, hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
-  c->helpers = kMaxHelpers;
+  c->helpers = kDefaultHelpers;
   return NDT_OK;
 }
 
@@ -502,33 +505,45 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   return NDT_OK;
 }
 
-// The build proper for an existing map object; any failure leaves the map without a speculative grid.
-static int map_build_impl(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size_t stride, const ndt_params *prm) {
+// The build in two halves.  build_begin queues everything: the bounding box of the cloud (getMinMax3D) with its
+// read-back on the side stream, and -- instead of idling the GPU during that round trip -- the rest of the build with
+// the voxel grid of the previous build of this map (a SLAM local map keeps its voxel bounding box for many scans).
+// build_end waits for the read-back, derives the grid on the host and queues the build again only if it differs.
+// Any failure leaves the map without a speculative grid.
+static int build_begin(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size_t stride, const ndt_params *prm) {
   hipStream_t st = ctx->stream;
   m->prm = *prm; m->n = n; m->info_valid = false;
+  m->pend_xy = xy; m->pend_stride = stride; m->pend_queued = false;
   HIP_TRY(ctx, hipEventRecord(ctx->evm0, st));
-
-  // 1. bounding box (getMinMax3D).  The grid follows from it on the host; instead of idling the GPU
-  // during that round trip, the rest of the build is queued at once with the grid of the previous
-  // build of this map (a SLAM local map keeps its voxel bounding box for many scans) and redone
-  // only if the read-back disagrees.
   // The bounding box (and the reset of the centroid grid, queue_build) run on a side stream beside the bucketing
   // chain -- a dozen dependent kernels whose launch latencies add up -- and are joined in front of the statistics.
   HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
   HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
   map_minmax_kernel<<<grid_for(n, 256 * 32, 128), 256, 0, ctx->side>>>(xy, stride, n, m->bounds, m->bounds + 4);
-  unsigned *hb = ctx->h_bounds;                // pinned
-  HIP_TRY(ctx, hipMemcpyAsync(hb, m->bounds + 4, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side));
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->h_bounds, m->bounds + 4, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side));
   HIP_TRY(ctx, hipEventRecord(ctx->evb, ctx->side));
   const float inv_leaf = 1.0f / prm->resolution;
-  bool queued = false;
   if (m->have_grid && m->grid.inv_leaf == inv_leaf) {
     int rc = queue_build(ctx, m, xy, n, stride, prm, m->grid);
     if (rc) return rc;
-    queued = true;
+    m->pend_queued = true;
+    HIP_TRY(ctx, hipEventRecord(ctx->evm1, st));           // what launches queued before build_end wait for
   }
+  m->pending = true;
+  ctx->pending_map = m;
+  return NDT_OK;
+}
+
+// Returns NDT_OK, or 1 if a build queued by build_begin used a grid that turned out wrong and has been queued again.
+static int build_end(ndt_ctx *ctx, ndt_map *m) {
+  hipStream_t st = ctx->stream;
+  const ndt_params *prm = &m->prm;
+  m->pending = false;
+  ctx->pending_map = nullptr;
+  const unsigned *hb = ctx->h_bounds;            // pinned
   HIP_TRY(ctx, hipEventSynchronize(ctx->evb));
   if (hb[0] == 0xffffffffu) return fail(ctx, NDT_E_ARG, "ndt_map_build: no finite points");
+  const float inv_leaf = 1.0f / prm->resolution;
   const float mnx = ord2f(hb[0]), mny = ord2f(hb[1]), mxx = ord2f(hb[2]), mxy = ord2f(hb[3]);
   GridDims G;
   G.inv_leaf = inv_leaf;
@@ -537,16 +552,26 @@ static int map_build_impl(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, s
   long long dy = (long long)(int)floorf(mxy * inv_leaf) - G.min_by + 1;
   if (dx * dy > (1LL << 28)) return fail(ctx, NDT_E_GRID, "ndt_map_build: voxel grid larger than 2^28 cells");
   G.div_x = (int)dx; G.div_y = (int)dy; G.gw = G.div_x + 4; G.gh = G.div_y + 4;
-  const bool same = queued && G.min_bx == m->grid.min_bx && G.min_by == m->grid.min_by &&
+  const bool same = m->pend_queued && G.min_bx == m->grid.min_bx && G.min_by == m->grid.min_by &&
                     G.div_x == m->grid.div_x && G.div_y == m->grid.div_y;
+  int redone = 0;
   if (!same) {
-    int rc = queue_build(ctx, m, xy, n, stride, prm, G);
+    int rc = queue_build(ctx, m, m->pend_xy, m->n, m->pend_stride, prm, G);
     if (rc) return rc;
+    redone = m->pend_queued ? 1 : 0;
   }
   m->grid = G; m->have_grid = true;
-  HIP_TRY(ctx, hipEventRecord(ctx->evm1, st));
+  if (!same) HIP_TRY(ctx, hipEventRecord(ctx->evm1, st));
   ctx->map_ms_pending = true;
-  return NDT_OK;                               // asynchronous from here on (stream order)
+  return redone;                               // asynchronous from here on (stream order)
+}
+
+static int map_build_impl(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size_t stride, const ndt_params *prm) {
+  if (ctx->pending_map) return fail(ctx, NDT_E_ARG, "ndt_map_build: ndt_map_rebuild_end is still owed for a map of this context");
+  int rc = build_begin(ctx, m, xy, n, stride, prm);
+  if (rc) { m->pending = false; ctx->pending_map = nullptr; return rc; }
+  rc = build_end(ctx, m);
+  return rc < 0 ? rc : NDT_OK;
 }
 
 int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, const ndt_params *prm,
@@ -580,6 +605,30 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, co
   return NDT_OK;
 }
 
+
+int ndt_map_rebuild_begin(ndt_ctx *ctx, const float *xy, size_t n, size_t stride, const ndt_params *prm, ndt_map *m) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!xy || n == 0 || !prm || !m || !(prm->resolution > 0) || stride < 8 || (stride & 7) || n > (size_t)INT32_MAX)
+    return fail(ctx, NDT_E_ARG, "ndt_map_rebuild_begin: bad arguments");
+  if (m->ctx != ctx) return fail(ctx, NDT_E_ARG, "ndt_map_rebuild_begin: the map belongs to another context");
+  if (ctx->pending_map) return fail(ctx, NDT_E_ARG, "ndt_map_rebuild_begin: ndt_map_rebuild_end is still owed for a map of this context");
+  if (!m->have_grid || m->grid.inv_leaf != 1.0f / prm->resolution)
+    return fail(ctx, NDT_E_ARG, "ndt_map_rebuild_begin: the map has no earlier build at this resolution (use ndt_map_build_dev)");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int rc = build_begin(ctx, m, xy, n, stride, prm);
+  if (rc) { m->have_grid = false; m->pending = false; ctx->pending_map = nullptr; }
+  return rc;
+}
+
+int ndt_map_rebuild_end(ndt_ctx *ctx, ndt_map *m) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!m || m->ctx != ctx || !m->pending || ctx->pending_map != m)
+    return fail(ctx, NDT_E_ARG, "ndt_map_rebuild_end: no ndt_map_rebuild_begin is open for this map");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const int rc = build_end(ctx, m);
+  if (rc < 0) m->have_grid = false;
+  return rc;
+}
 
 int ndt_map_build(ndt_ctx *ctx, const float *xy_host, size_t n, size_t stride, const ndt_params *prm,
                   ndt_map **pmap) {

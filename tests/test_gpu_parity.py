@@ -90,6 +90,39 @@ def test_map_rebuild_in_place(gpu, oracle, c1_world):
     assert np.array_equal(g["idx"], o["idx"]) and np.array_equal(g["cent"], o["cent"])
 
 
+def test_two_phase_rebuild(gpu, oracle, c1_world):
+    """ndt_map_rebuild_begin / _end: the build is queued with the grid of the previous build; _end reports whether the
+    cloud's bounding box had moved (then the build has been queued again).  Either way the map equals a fresh build."""
+    import torch
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    prm = capi.default_params(resolution=cfg["resolution"])
+    gm = capi.Map(ctx, m, prm)
+    scan, truth, init = sf.make(2)
+    first = gm.align(scan, init)
+    d_m = torch.from_numpy(m).cuda()
+    torch.cuda.synchronize()
+    gm.rebuild_begin(d_m.data_ptr(), len(m), 8)
+    with pytest.raises(RuntimeError):
+        gm.rebuild(xy=m)                                   # one rebuild in flight per context
+    assert gm.rebuild_end() is False                       # same cloud: the speculative grid was the right one
+    with pytest.raises(RuntimeError):
+        gm.rebuild_end()                                   # nothing open any more
+    assert gm.align(scan, init).tobytes() == first.tobytes()
+    moved = (m + np.array([7.3, -4.1], np.float32)).astype(np.float32)
+    d_m2 = torch.from_numpy(moved).cuda()
+    torch.cuda.synchronize()
+    gm.rebuild_begin(d_m2.data_ptr(), len(moved), 8)
+    assert gm.rebuild_end() is True                        # bounding box moved: queued again with the new grid
+    g, o = gm.export(), oracle.Map(moved, oracle.default_params(resolution=cfg["resolution"])).export()
+    for k in ("idx", "npts", "cent", "mean"):
+        assert np.array_equal(g[k], o[k]), k
+    other = capi.Map(ctx, m, capi.default_params(resolution=2 * cfg["resolution"]))
+    other.params = prm
+    with pytest.raises(RuntimeError):
+        other.rebuild_begin(d_m.data_ptr(), len(m), 8)     # no earlier build at this resolution
+
+
 # ------------------------------------------------------------------------------------------ a4 + a5
 def test_single_evaluation_matches_oracle(gpu, oracle, c1_world):
     capi, ctx = gpu
@@ -265,6 +298,10 @@ def test_results_do_not_depend_on_work_sharing(gpu):
     solo_ctx.set_option(capi.OPT_MAX_HELPERS, 0)
     solo = capi.Map(solo_ctx, m, prm).align_batch(scans, off, inits)
     assert np.all(shared["status"] == 0) and shared.tobytes() == solo.tobytes()
+    most_ctx = capi.Context(0)
+    most_ctx.set_option(capi.OPT_MAX_HELPERS, 15)            # the hard limit (default: 8)
+    most = capi.Map(most_ctx, m, prm).align_batch(scans, off, inits)
+    assert most.tobytes() == solo.tobytes()
 
 
 def test_ragged_batch_with_more_scans_than_workgroups(gpu, oracle, c1_world):
