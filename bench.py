@@ -92,7 +92,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=["C3", "C5"], default="C3",
                     help="C3: 256 scans x 10k vs 1M map per GPU (configs[2]/[3]); C5: 512 seeds x one scan vs 5M map per GPU (configs[4])")
     ap.add_argument("--batch", type=int, default=None, help="matches per GPU and step (default 256 for C3, 512 for C5)")
