@@ -148,7 +148,8 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy_dev, size_t n, size_t stride
  * build, and returns; launches queued behind it see that build.  _end waits for the bounding box: NDT_OK if the grid
  * was the right one (a SLAM local map keeps its voxel bounding box for many scans, src/PointCloudMap.cpp:119-131),
  * NDT_REBUILT if it was not -- the build has been queued again, and whatever was queued between _begin and _end ran on
- * a stale grid and has to be queued again by the caller.  One _begin may be open per context.  The map must have been
+ * a stale grid and has to be queued again by the caller.  One _begin may be open per context (other builds on that
+ * context fail with NDT_E_ARG until _end); xy_dev must stay as it is until _end has returned.  The map must have been
  * built before at the same resolution. */
 #define NDT_REBUILT 1
 int ndt_map_rebuild_begin(ndt_ctx *ctx, const float *xy_dev, size_t n, size_t stride_bytes,
