@@ -371,6 +371,43 @@ def test_multi_hypothesis_shared_scan(gpu, oracle, c1_world):
     assert best == int(np.argmax(ref_all))
 
 
+def test_pointxyz_records_equal_packed_points(gpu, c1_world):
+    """`pcl::PointXYZ` records (16 bytes: x, y, z, pad -- what the reference's clouds hold) go in as they are
+    (stride_bytes = 16, packed on the device): map, match and fitness equal the packed float2 path byte for byte."""
+    import ctypes as C
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    prm = capi.default_params(resolution=cfg["resolution"])
+    scan, truth, init = sf.make(5)
+
+    def xyz(a):
+        out = np.full((len(a), 4), 7.25, np.float32)      # z and the pad word must not matter
+        out[:, :2] = a
+        return np.ascontiguousarray(out)
+
+    m16, s16 = xyz(m), xyz(scan)
+    packed = capi.Map(ctx, m, prm)
+    ref = packed.align(scan, init)
+    h = C.c_void_p()
+    ctx.check(capi.lib().ndt_map_build(ctx.h, m16.ctypes.data, len(m16), 16, C.byref(prm), C.byref(h)), "ndt_map_build stride 16")
+    try:
+        wide = capi.Map.__new__(capi.Map)
+        wide.ctx, wide.params, wide.h = ctx, prm, h
+        g, o = wide.export(), packed.export()
+        for k in ("idx", "npts", "cent", "mean", "icov"):
+            assert np.array_equal(g[k], o[k]), k
+        res = np.zeros(1, dtype=capi.RESULT_DTYPE)
+        i64 = np.ascontiguousarray(init, dtype=np.float64)
+        ctx.check(capi.lib().ndt_align(ctx.h, h, s16.ctypes.data, len(s16), 16, i64.ctypes.data, res.ctypes.data), "ndt_align stride 16")
+        assert res[0].tobytes() == ref.tobytes()
+        f = C.c_double()
+        ctx.check(capi.lib().ndt_fitness_at(ctx.h, h, s16.ctypes.data, len(s16), 16, ref["T00"], ref["T10"], ref["T03"], ref["T13"],
+                                           C.addressof(f)), "ndt_fitness_at stride 16")
+        assert f.value == packed.fitness_at(scan, ref["T00"], ref["T10"], ref["T03"], ref["T13"])
+    finally:
+        wide.close()
+
+
 def test_error_behaviour(gpu):
     capi, ctx = gpu
     with pytest.raises(capi.NdtError):
