@@ -37,10 +37,13 @@ def build(force=False, verbose=False, extra=(), out=None):
 
 
 if __name__ == "__main__":
-    # python -m ndt_slam_amd.build [--force] [--usage] [--out PATH] [-DNAME[=V] ...]
+    # python -m ndt_slam_amd.build [--force] [--usage] [--out PATH] [-DNAME[=V] ...] [--flag=<hipcc flag> ...]
     argv = sys.argv[1:]
     out = argv[argv.index("--out") + 1] if "--out" in argv else None
     extra = [a for a in argv if a.startswith("-D")]
+    for a in argv:                                     # experiments: --flag=-mllvm --flag=-amdgpu-... passed through to hipcc
+        if a.startswith("--flag="):
+            extra.append(a[len("--flag="):])
     if "--usage" in argv:
         extra.append("-Rpass-analysis=kernel-resource-usage")
     print(build(force="--force" in argv, verbose=True, extra=extra, out=out))
