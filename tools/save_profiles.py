@@ -75,10 +75,12 @@ traffic = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, mean over the match kernel's launches of "
               "`bench.py --no-single-scan --no-cpu-baseline --steps 8` (profiles/%spmc_fetch.csv, %spmc_write.csv)" % (pre, pre),
     "fetch_size_kb": mean["FETCH_SIZE"], "write_size_kb": mean["WRITE_SIZE"],
-    "bytes_per_launch": (mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0,
-    "note": "raw counters x 1024 (rocprofv3 reports KB).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads half the bytes "
-            "of wide coalesced streaming reads; this kernel's reads are mostly 8-byte gathers and record loads, a pattern "
-            "the guide leaves uncalibrated, so the figure is not doubled (upper bound with doubling: fetch x 2)."}
+    "bytes_per_launch": (2.0 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024.0,
+    "note": "(2 x FETCH_SIZE + WRITE_SIZE) x 1024 (rocprofv3 reports KB).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads half "
+            "the bytes of wide coalesced streaming reads and other widths are to be calibrated: tools/repro/calib_fetch.hip "
+            "(profiles/r02_calib_fetch.txt) reads a 64 MiB buffer with this kernel's access widths -- 4, 8, 16 bytes per lane, "
+            "48-byte records, 8-byte gathers one line apart -- and FETCH_SIZE is 0.500 x the bytes of the 128-byte lines "
+            "touched in every case, so the fetch counter is doubled; WRITE_SIZE is exact per the guide."}
 json.dump(traffic, open(os.path.join(P, pre + "traffic.json"), "w"), indent=1)
 
 if "SQ_INSTS_VALU" in mean:
