@@ -179,7 +179,7 @@ prefilter_offsets_kernel(const unsigned *__restrict__ counts, int B, unsigned lo
     sh[threadIdx.x] = v;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
-      const unsigned long long t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0ull;
+      const unsigned long long t = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0ull;
       __syncthreads();
       sh[threadIdx.x] += t;
       __syncthreads();
@@ -419,7 +419,7 @@ remove_neighbors_scan_kernel(int *__restrict__ block_count, int nblocks, unsigne
     sh[threadIdx.x] = v;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {
-      const int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+      const int t = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
       __syncthreads();
       sh[threadIdx.x] += t;
       __syncthreads();

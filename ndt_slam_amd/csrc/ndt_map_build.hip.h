@@ -150,7 +150,7 @@ scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ 
   sh[threadIdx.x] = s;
   __syncthreads();
   for (int o = 1; o < kScanBlock; o <<= 1) {
-    int t = threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+    int t = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
     __syncthreads();
     sh[threadIdx.x] += t;
     __syncthreads();
@@ -310,7 +310,7 @@ __device__ int leaf_finalize(const LeafParams &L, int n, double sx, double sy, d
 // Cell record of one voxel from its sums (shared by the two kernels below).
 __device__ __forceinline__ int write_voxel(const GridDims &G, const LeafParams &L, size_t g, int n, float fx, float fy,
                                            double sx, double sy, double sxx, double sxy, double syy, double szz,
-                                           float2 *__restrict__ cent, double *__restrict__ rec, int *__restrict__ counters) {
+                                           float2 *__restrict__ cent, double *__restrict__ rec, int *__restrict__ /* counters: unused */) {
   if (n < L.min_pts) return 0;
   const int ix = (int)(g % G.div_x), iy = (int)(g / G.div_x);
   const size_t pg = (size_t)(iy + 2) * G.gw + (ix + 2);

@@ -1038,10 +1038,11 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       if (wave == 0) {
         // wave 0 polls line 0 of the scan's control block: lane 0 the epoch word, lanes 1..12 the pose halves.  A new
         // epoch that counts this helper in is taken once every pose word carries its tag as well.
-        u64 word = 0, mine = 0, mine_next = 0;
+        u64 word = 0, mine = 0;
         unsigned polls = 0;
         const u64 w0 = wall_clock64();
 #if NDT_POLL2H
+        u64 mine_next = 0;
         if (lane <= kPoseWords) mine_next = ld64(&C->ticket + lane);   // two polls in flight: half the time between looks
 #endif
         for (unsigned it = 0; it < 0x40000000u; ++it) {
