@@ -643,8 +643,10 @@ static double fitness_pass(const ndt_oracle_map *m, const float *scan, size_t n,
     float qx, qy; tf_apply(&m->prm, T, p[0], p[1], &qx, &qy);
     if (!isfinite(qx) || !isfinite(qy)) continue;
     int cx = vox_coord(qx, m->inv_leaf) - m->min_bx, cy = vox_coord(qy, m->inv_leaf) - m->min_by;
-    if (cx < 0) cx = 0; if (cx >= m->div_x) cx = m->div_x - 1;
-    if (cy < 0) cy = 0; if (cy >= m->div_y) cy = m->div_y - 1;
+    if (cx < 0) cx = 0;
+    if (cx >= m->div_x) cx = m->div_x - 1;
+    if (cy < 0) cy = 0;
+    if (cy >= m->div_y) cy = m->div_y - 1;
     float best = INFINITY;
     int rmax = (m->div_x > m->div_y ? m->div_x : m->div_y);
     for (int r = 0; r <= rmax; ++r) {
