@@ -1,6 +1,6 @@
 """Soak of the work-sharing protocol: many launches of the bench batch (and a ragged one), every result compared
 with the first launch bit for bit; any watchdog abort, hang or race shows up as a status or a mismatch.
-Usage: python tools/soak.py [launches] [B]"""
+Usage: python tools/soak.py [launches] [B] [shared]   (shared: B seed poses of ONE scan, `shared_scan`, as configs[4])"""
 import os
 import sys
 import time
@@ -15,10 +15,16 @@ from ndt_slam_amd import capi, synth               # noqa: E402
 def main():
     launches = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+    shared = len(sys.argv) > 3 and sys.argv[3] == "shared"
     cfg = synth.CONFIGS["C3"]
     m = synth.make_map(cfg["n_map"], cfg["half"])
     sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
     scans, off, truths, inits = sf.batch(0, B)
+    if shared:                                       # one scan, B hypotheses around its true pose
+        scans, truth, _ = sf.make(0)
+        off = np.array([0, len(scans)], np.uint64)
+        inits = synth.hypothesis_seeds(truth, 4096)[::max(1, 4096 // B)][:B]
+        B = len(inits)
     if B % 2:                                        # ragged: shorten every third scan
         keep = np.ones(len(scans), bool)
         for b in range(0, B, 3):
@@ -39,7 +45,7 @@ def main():
     t0 = time.time()
     for it in range(launches):
         gm.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, len(scans), d_init.data_ptr(), d_res.data_ptr(),
-                           stream=stream.cuda_stream)
+                           shared_scan=shared, stream=stream.cuda_stream)
         if it % 50 == 0 or it == launches - 1:
             stream.synchronize()
             r = d_res.cpu().numpy().tobytes()
@@ -52,7 +58,7 @@ def main():
                 print("launch", it, "differs from launch 0"); bad += 1
         if it % 1000 == 0:
             print("launch", it, "%.1f s" % (time.time() - t0), flush=True)
-    print("soak: %d launches of B=%d, %d problems, %.1f s" % (launches, B, bad, time.time() - t0))
+    print("soak: %d launches of B=%d%s, %d problems, %.1f s" % (launches, B, " (shared scan)" if shared else "", bad, time.time() - t0))
     sys.exit(1 if bad else 0)
 
 
