@@ -14,7 +14,10 @@
 // ------------------------------------------------------------------------------------------
 constexpr int kPfSlots = 512;
 struct __attribute__((aligned(8))) PfSlot { int ix, iy, cnt; float cx, cy; int pad; };   // 24 B: one b128 + one b64 LDS read
-constexpr int kPfWaveBits = 2, kPfWaves = 1 << kPfWaveBits, kPfQueue = 128, kPfMaxPoints = 1 << 18;   // bitmap: 32 KiB of LDS
+#ifndef NDT_PF_WAVE_BITS
+#define NDT_PF_WAVE_BITS 3
+#endif
+constexpr int kPfWaveBits = NDT_PF_WAVE_BITS, kPfWaves = 1 << kPfWaveBits, kPfQueue = 128, kPfMaxPoints = 1 << 18;   // bitmap: 32 KiB of LDS
 __global__ void __launch_bounds__(64 * kPfWaves)
 prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
                     float leaf, float2 *__restrict__ sparse /* at the raw offsets */,
