@@ -14,6 +14,9 @@
 // ------------------------------------------------------------------------------------------
 constexpr int kPfSlots = 512;
 struct __attribute__((aligned(8))) PfSlot { int ix, iy, cnt; float cx, cy; int pad; };   // 24 B: one b128 + one b64 LDS read
+#ifndef NDT_PF_AHEAD
+#define NDT_PF_AHEAD 8
+#endif
 #ifndef NDT_PF_WAVE_BITS
 #define NDT_PF_WAVE_BITS 3
 #endif
@@ -70,28 +73,47 @@ prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned 
         }
       };
       int qn = 0;
-      float2 pnext = make_float2(0.f, 0.f);
-      if (lane < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)lane);
-      for (int base = 0; base < n; base += 64) {
-        const int i = base + lane;
-        const float2 p = pnext;
-        if (i + 64 < n) pnext = load_pt(xy, stride, (size_t)o0 + (size_t)(i + 64));
-        const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
-        const unsigned h = ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);
-        const bool mine = i < n && (int)(h & (unsigned)(kPfWaves - 1)) == w;
-        const unsigned long long mb = __ballot(mine);
-        if (mine) { const int pos = qn + __builtin_popcountll(mb & lt); qpt[w][pos] = p; qidx[w][pos] = i; }
-        qn += __builtin_popcountll(mb);
-        __builtin_amdgcn_wave_barrier();
-        if (qn >= 64) {
-          replay(64);
-          const int rest = qn - 64;                           // < 64: move the tail to the front
-          float2 tp = make_float2(0.f, 0.f); int ti = 0;
-          if (lane < rest) { tp = qpt[w][64 + lane]; ti = qidx[w][64 + lane]; }
+      // the read-hash-queue pass over the whole scan: kPfAhead steps of 64 points are in flight (one step ahead left
+      // every step waiting for its load: 0.6 us a step, most of the kernel)
+      constexpr int kPfAhead = NDT_PF_AHEAD;
+      float2 pnext[kPfAhead];
+#pragma unroll
+      for (int u = 0; u < kPfAhead; ++u) {
+        const int i = 64 * u + lane;
+        pnext[u] = i < n ? load_pt(xy, stride, (size_t)o0 + (size_t)i) : make_float2(0.f, 0.f);
+      }
+      for (int base0 = 0; base0 < n; base0 += 64 * kPfAhead) {
+        float2 pcur[kPfAhead];
+#pragma unroll
+        for (int u = 0; u < kPfAhead; ++u) pcur[u] = pnext[u];
+#pragma unroll
+        for (int u = 0; u < kPfAhead; ++u) {
+          const int i = base0 + 64 * (kPfAhead + u) + lane;
+          pnext[u] = i < n ? load_pt(xy, stride, (size_t)o0 + (size_t)i) : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < kPfAhead; ++u) {
+          const int base = base0 + 64 * u;
+          if (base >= n) break;
+          const int i = base + lane;
+          const float2 p = pcur[u];
+          const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
+          const unsigned h = ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);
+          const bool mine = i < n && (int)(h & (unsigned)(kPfWaves - 1)) == w;
+          const unsigned long long mb = __ballot(mine);
+          if (mine) { const int pos = qn + __builtin_popcountll(mb & lt); qpt[w][pos] = p; qidx[w][pos] = i; }
+          qn += __builtin_popcountll(mb);
           __builtin_amdgcn_wave_barrier();
-          if (lane < rest) { qpt[w][lane] = tp; qidx[w][lane] = ti; }
-          __builtin_amdgcn_wave_barrier();
-          qn = rest;
+          if (qn >= 64) {
+            replay(64);
+            const int rest = qn - 64;                           // < 64: move the tail to the front
+            float2 tp = make_float2(0.f, 0.f); int ti = 0;
+            if (lane < rest) { tp = qpt[w][64 + lane]; ti = qidx[w][64 + lane]; }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < rest) { qpt[w][lane] = tp; qidx[w][lane] = ti; }
+            __builtin_amdgcn_wave_barrier();
+            qn = rest;
+          }
         }
       }
       if (qn > 0) replay(qn);
