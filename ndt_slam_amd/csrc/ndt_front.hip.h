@@ -14,6 +14,9 @@
 // ------------------------------------------------------------------------------------------
 constexpr int kPfSlots = 512;
 struct __attribute__((aligned(8))) PfSlot { int ix, iy, cnt; float cx, cy; int pad; };   // 24 B: one b128 + one b64 LDS read
+#ifndef NDT_PF_SORTED
+#define NDT_PF_SORTED 1   // 0: every scan through the step-by-step replay (A/B)
+#endif
 #ifndef NDT_PF_AHEAD
 #define NDT_PF_AHEAD 8
 #endif
@@ -24,7 +27,8 @@ constexpr int kPfWaveBits = NDT_PF_WAVE_BITS, kPfWaves = 1 << kPfWaveBits, kPfQu
 __global__ void __launch_bounds__(64 * kPfWaves)
 prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
                     float leaf, float2 *__restrict__ sparse /* at the raw offsets */,
-                    float2 *__restrict__ tmp /* at the raw offsets: dense result */, unsigned *__restrict__ counts) {
+                    float2 *__restrict__ tmp /* at the raw offsets: dense result */, unsigned *__restrict__ counts,
+                    int skip_up_to /* scans of at most this many points are another kernel's */) {
   __shared__ PfSlot slot[kPfSlots];
   __shared__ float2 qpt[kPfWaves][kPfQueue];
   __shared__ int qidx[kPfWaves][kPfQueue];
@@ -36,6 +40,7 @@ prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned 
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const unsigned long long o0 = offsets[b];
     const int n = (int)(offsets[b + 1] - o0);
+    if (n <= skip_up_to) continue;                           // (uniform over the workgroup)
     __syncthreads();
     for (int h = threadIdx.x; h < kPfSlots; h += 64 * kPfWaves) { PfSlot z; z.ix = 0; z.iy = 0; z.cnt = 0; z.cx = 0.f; z.cy = 0.f; z.pad = 0; slot[h] = z; }
     const int nwords = (min(n, kPfMaxPoints) + 31) / 32;
@@ -179,6 +184,190 @@ prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned 
     __syncthreads();
     if (w == 0) {                                            // what is left, in slot order
       if (n > kPfMaxPoints) nout = __builtin_amdgcn_readfirstlane(nout);
+      for (int h0 = 0; h0 < kPfSlots; h0 += 64) {
+        const PfSlot e = slot[h0 + lane];
+        const unsigned long long fb = __ballot(e.cnt > 0);
+        if (e.cnt > 0) tmp[o0 + (unsigned long long)(nout + __builtin_popcountll(fb & lt))] =
+            make_float2(e.cx / (float)e.cnt, e.cy / (float)e.cnt);
+        nout += __builtin_popcountll(fb);
+      }
+      if (lane == 0) counts[b] = (unsigned)nout;
+    }
+  }
+}
+
+// The same filter for scans of up to kPfSortMax points, organised by SLOT instead of by step.  The 512 slots are
+// independent state machines, and what a slot does depends only on the points that hash to it, in cloud order: so the
+// points are first ordered by slot -- a stable counting sort of their numbers in LDS: every wave counts and later places
+// the points of its own contiguous part of the scan, step by step in cloud order, a lane's turn among equal slots inside
+// a step from ballots -- and then thread h walks the points of slot h with the slot's state in registers, one after the
+// other, its loads in flight ahead of it.  No lane ever waits for its turn on a slot, and every point is looked at by
+// one lane per pass instead of by each of eight waves.  The walk is made twice: first only to mark the points that cause
+// a flush (a bitmap in LDS), then -- a prefix sum over the bitmap later -- to write every flush straight to its place in
+// the output, the rank of its point among the marked ones: the order the sequential filter emits them in.  (Parking the
+// flushes at the index of their cause and compacting afterwards moved 64 bytes of memory per 8-byte flush, twice.)  The
+// slots left over follow in slot order -- the reference's output, bit for bit (tests/test_gpu_prefilter.py).
+constexpr int kPfSortMax = 32768, kPfSortThreads = 512, kPfSortWaves = kPfSortThreads / 64;
+__global__ void __launch_bounds__(kPfSortThreads)
+prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
+                        float leaf, float2 *__restrict__ tmp /* at the raw offsets: dense result */,
+                        unsigned *__restrict__ counts) {
+  __shared__ unsigned short order[kPfSortMax];                  // point numbers, ordered by slot, cloud order inside a slot
+  __shared__ unsigned short wcount[kPfSortWaves][kPfSlots];      // pass 1: points of wave w's part in slot h; then: where they go
+  __shared__ int sbase[kPfSlots + 1];                           // first position of slot h in `order`
+  __shared__ PfSlot slot[kPfSlots];
+  __shared__ unsigned fbits[kPfSortMax / 32];                   // point i causes a flush
+  __shared__ unsigned short fpre[kPfSortMax / 32];              // marked points in front of word k
+  __shared__ int wsum[kPfSortWaves + 1];
+  static_assert(kPfSortThreads == kPfSlots, "one thread per slot");
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const float inv = 1.0f / leaf;
+  constexpr int kAhead = 4;
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const unsigned long long o0 = offsets[b];
+    const int n = (int)(offsets[b + 1] - o0);
+    if (n > kPfSortMax || !NDT_PF_SORTED) continue;            // prefilter_mw_kernel's (uniform over the workgroup)
+    __syncthreads();
+    for (int i = threadIdx.x; i < kPfSortWaves * kPfSlots; i += kPfSortThreads) (&wcount[0][0])[i] = 0;
+    const int nwords = (n + 31) / 32;
+    for (int i = threadIdx.x; i < nwords; i += kPfSortThreads) fbits[i] = 0u;
+    __syncthreads();
+    // ---- the part of the scan this wave counts and places: whole steps of 64 points
+    const int steps = (n + 63) / 64, spw = (steps + kPfSortWaves - 1) / kPfSortWaves;
+    const int s0 = min(w * spw, steps), s1 = min(s0 + spw, steps);
+    auto slot_of = [&](float2 p) {
+      const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
+      return ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);
+    };
+    // the lanes of a step that share a slot
+    auto peers_of = [&](bool active, unsigned h) {
+      unsigned long long peers = __ballot(active);
+#pragma unroll
+      for (int bit = 0; bit < 9; ++bit) {
+        const unsigned long long one = __ballot(active && ((h >> bit) & 1u));
+        peers &= ((h >> bit) & 1u) ? one : ~one;
+      }
+      return peers;
+    };
+    // ---- pass 1: how many points of this wave's part fall into every slot
+    for (int sg = s0; sg < s1; sg += kAhead) {
+      float2 p[kAhead];
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const int i = (sg + u) * 64 + lane;
+        p[u] = (sg + u < s1 && i < n) ? load_pt(xy, stride, (size_t)o0 + (size_t)i) : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        if (sg + u >= s1) break;
+        const int i = (sg + u) * 64 + lane;
+        const bool active = i < n;
+        const unsigned h = slot_of(p[u]);
+        const unsigned long long peers = peers_of(active, h);
+        if (active && (peers & lt) == 0ull) wcount[w][h] = (unsigned short)(wcount[w][h] + __builtin_popcountll(peers));   // first of its group
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    // ---- slot h: its total, the offsets of the waves' shares inside it, then the exclusive scan of the totals
+    {
+      const int h = threadIdx.x;
+      int run = 0;
+#pragma unroll
+      for (int k = 0; k < kPfSortWaves; ++k) { const int c = wcount[k][h]; wcount[k][h] = (unsigned short)run; run += c; }
+      int incl = run;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      if (lane == 63) wsum[w] = incl;
+      __syncthreads();
+      int base = incl - run;
+      for (int k = 0; k < w; ++k) base += wsum[k];
+      sbase[h] = base;
+      if (h == kPfSlots - 1) sbase[kPfSlots] = base + run;
+    }
+    __syncthreads();
+    // ---- pass 2: every point's number to its place (slot base + the wave's offset in the slot + turn in the step)
+    for (int sg = s0; sg < s1; sg += kAhead) {
+      float2 p[kAhead];
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        const int i = (sg + u) * 64 + lane;
+        p[u] = (sg + u < s1 && i < n) ? load_pt(xy, stride, (size_t)o0 + (size_t)i) : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < kAhead; ++u) {
+        if (sg + u >= s1) break;
+        const int i = (sg + u) * 64 + lane;
+        const bool active = i < n;
+        const unsigned h = slot_of(p[u]);
+        const unsigned long long peers = peers_of(active, h);
+        const int turn = __builtin_popcountll(peers & lt);
+        int at = 0;
+        if (active) at = sbase[h] + wcount[w][h];
+        __builtin_amdgcn_wave_barrier();                       // all lanes of the group have read the wave's offset
+        if (active) {
+          order[at + turn] = (unsigned short)i;
+          if (turn == 0) wcount[w][h] = (unsigned short)(wcount[w][h] + __builtin_popcountll(peers));
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __syncthreads();
+    // ---- slot h, one thread: its points in cloud order.  mark: only note which points cause a flush; else: write the flushes
+    const int h = threadIdx.x;
+    const int seg_a = sbase[h], seg_e = sbase[h + 1];
+    auto walk = [&](bool mark) {
+      int six = 0, siy = 0, cnt = 0; float cx = 0.f, cy = 0.f;
+      constexpr int kWide = 8;
+      for (int k0 = seg_a; k0 < seg_e; k0 += kWide) {
+        int idx[kWide]; float2 p[kWide];
+#pragma unroll
+        for (int u = 0; u < kWide; ++u) idx[u] = order[min(k0 + u, seg_e - 1)];
+#pragma unroll
+        for (int u = 0; u < kWide; ++u) p[u] = load_pt(xy, stride, (size_t)o0 + (size_t)idx[u]);
+#pragma unroll
+        for (int u = 0; u < kWide; ++u) {
+          if (k0 + u >= seg_e) break;
+          const int ix = (int)floorf(p[u].x * inv), iy = (int)floorf(p[u].y * inv);
+          if (cnt && (ix != six || iy != siy)) {
+            const int i = idx[u];
+            if (mark) {
+              atomicOr(&fbits[i >> 5], 1u << (i & 31));
+            } else {
+              const int rank = (int)fpre[i >> 5] + __builtin_popcount(fbits[i >> 5] & ((1u << (i & 31)) - 1u));
+              tmp[o0 + (unsigned long long)rank] = make_float2(cx / (float)cnt, cy / (float)cnt);
+            }
+            cnt = 0; cx = 0.f; cy = 0.f;
+          }
+          six = ix; siy = iy; cnt += 1; cx += p[u].x; cy += p[u].y;
+        }
+      }
+      if (!mark) { PfSlot z; z.ix = six; z.iy = siy; z.cnt = cnt; z.cx = cx; z.cy = cy; z.pad = 0; slot[h] = z; }
+    };
+    walk(true);
+    __syncthreads();
+    // ---- marked points in front of every word of the bitmap
+    int nout = 0;
+    {
+      int mine_cnt = 0;
+      const int per = (nwords + kPfSortThreads - 1) / kPfSortThreads;
+      const int w0 = min((int)threadIdx.x * per, nwords), w1 = min(w0 + per, nwords);
+      for (int k = w0; k < w1; ++k) mine_cnt += __builtin_popcount(fbits[k]);
+      int incl = mine_cnt;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+      if (lane == 63) wsum[w] = incl;                          // (the slot scan's use of wsum ended two barriers ago)
+      __syncthreads();
+      int off = incl - mine_cnt;
+      for (int k = 0; k < w; ++k) off += wsum[k];
+      for (int k = 0; k < kPfSortWaves; ++k) nout += wsum[k];
+      for (int k = w0; k < w1; ++k) { fpre[k] = (unsigned short)off; off += __builtin_popcount(fbits[k]); }
+    }
+    __syncthreads();
+    walk(false);
+    __syncthreads();
+    if (w == 0) {                                              // what is left, in slot order
       for (int h0 = 0; h0 < kPfSlots; h0 += 64) {
         const PfSlot e = slot[h0 + lane];
         const unsigned long long fb = __ballot(e.cnt > 0);

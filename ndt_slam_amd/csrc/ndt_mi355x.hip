@@ -935,8 +935,11 @@ int ndt_prefilter_batch_dev(ndt_ctx *ctx, const float *raw_xy, size_t stride, co
   float2 *sparse = (float2 *)((char *)ctx->d_pf + tmp_bytes);          // flushes at the index of their cause
   unsigned *counts = (unsigned *)((char *)ctx->d_pf + 2 * tmp_bytes);
   const int grid = B < 8 * ctx->num_cus ? B : 8 * ctx->num_cus;
+  // scans of up to kPfSortMax points: ordered by slot, one thread per slot; longer ones: the step-by-step replay
+  prefilter_sorted_kernel<<<grid, kPfSortThreads, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf,
+                                                           tmp, counts);
   prefilter_mw_kernel<<<grid, 64 * kPfWaves, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf,
-                                                      sparse, tmp, counts);
+                                                      sparse, tmp, counts, NDT_PF_SORTED ? kPfSortMax : -1);
   prefilter_offsets_kernel<<<1, 1024, 0, st>>>(counts, B, (unsigned long long *)out_offsets);
   const int gx = (int)std::min<size_t>(64, (total_raw_points / (size_t)B + 255) / 256 + 1);
   prefilter_pack_kernel<<<dim3((unsigned)gx, (unsigned)std::min(B, 65535)), 256, 0, st>>>(
