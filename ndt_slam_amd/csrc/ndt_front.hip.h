@@ -202,16 +202,15 @@ prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned 
 // the points of its own contiguous part of the scan, step by step in cloud order, a lane's turn among equal slots inside
 // a step from ballots -- and then thread h walks the points of slot h with the slot's state in registers, one after the
 // other, its loads in flight ahead of it.  No lane ever waits for its turn on a slot, and every point is looked at by
-// one lane per pass instead of by each of eight waves.  The walk is made twice: first only to mark the points that cause
-// a flush (a bitmap in LDS), then -- a prefix sum over the bitmap later -- to write every flush straight to its place in
-// the output, the rank of its point among the marked ones: the order the sequential filter emits them in.  (Parking the
-// flushes at the index of their cause and compacting afterwards moved 64 bytes of memory per 8-byte flush, twice.)  The
-// slots left over follow in slot order -- the reference's output, bit for bit (tests/test_gpu_prefilter.py).
+// one lane per pass instead of by each of eight waves.  A flush is parked at the index of the point that caused it and
+// marked in a bitmap in LDS; a prefix sum over the bitmap later, flush number r -- the r-th marked point: the order the
+// sequential filter emits them in -- is copied to its place by a thread of its own.  The slots left over follow in slot
+// order -- the reference's output, bit for bit (tests/test_gpu_prefilter.py).
 constexpr int kPfSortMax = 32768, kPfSortThreads = 512, kPfSortWaves = kPfSortThreads / 64;
 __global__ void __launch_bounds__(kPfSortThreads)
 prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
-                        float leaf, float2 *__restrict__ tmp /* at the raw offsets: dense result */,
-                        unsigned *__restrict__ counts) {
+                        float leaf, float2 *__restrict__ sparse /* at the raw offsets: flushes at the index of their cause */,
+                        float2 *__restrict__ tmp /* at the raw offsets: dense result */, unsigned *__restrict__ counts) {
   __shared__ unsigned short order[kPfSortMax];                  // point numbers, ordered by slot, cloud order inside a slot
   __shared__ unsigned short wcount[kPfSortWaves][kPfSlots];      // pass 1: points of wave w's part in slot h; then: where they go
   __shared__ int sbase[kPfSlots + 1];                           // first position of slot h in `order`
@@ -317,7 +316,7 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
     // ---- slot h, one thread: its points in cloud order.  mark: only note which points cause a flush; else: write the flushes
     const int h = threadIdx.x;
     const int seg_a = sbase[h], seg_e = sbase[h + 1];
-    auto walk = [&](bool mark) {
+    {
       int six = 0, siy = 0, cnt = 0; float cx = 0.f, cy = 0.f;
       constexpr int kWide = 8;
       for (int k0 = seg_a; k0 < seg_e; k0 += kWide) {
@@ -330,22 +329,18 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
         for (int u = 0; u < kWide; ++u) {
           if (k0 + u >= seg_e) break;
           const int ix = (int)floorf(p[u].x * inv), iy = (int)floorf(p[u].y * inv);
-          if (cnt && (ix != six || iy != siy)) {
+          if (cnt && (ix != six || iy != siy)) {               // flush: parked at the index of the point that caused it
             const int i = idx[u];
-            if (mark) {
-              atomicOr(&fbits[i >> 5], 1u << (i & 31));
-            } else {
-              const int rank = (int)fpre[i >> 5] + __builtin_popcount(fbits[i >> 5] & ((1u << (i & 31)) - 1u));
-              tmp[o0 + (unsigned long long)rank] = make_float2(cx / (float)cnt, cy / (float)cnt);
-            }
+            sparse[o0 + (unsigned long long)i] = make_float2(cx / (float)cnt, cy / (float)cnt);
+            atomicOr(&fbits[i >> 5], 1u << (i & 31));
             cnt = 0; cx = 0.f; cy = 0.f;
           }
           six = ix; siy = iy; cnt += 1; cx += p[u].x; cy += p[u].y;
         }
       }
-      if (!mark) { PfSlot z; z.ix = six; z.iy = siy; z.cnt = cnt; z.cx = cx; z.cy = cy; z.pad = 0; slot[h] = z; }
-    };
-    walk(true);
+      PfSlot z; z.ix = six; z.iy = siy; z.cnt = cnt; z.cx = cx; z.cy = cy; z.pad = 0;
+      slot[h] = z;
+    }
     __syncthreads();
     // ---- marked points in front of every word of the bitmap
     int nout = 0;
@@ -365,7 +360,17 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
       for (int k = w0; k < w1; ++k) { fpre[k] = (unsigned short)off; off += __builtin_popcount(fbits[k]); }
     }
     __syncthreads();
-    walk(false);
+    // ---- the flushes in the order of the points that caused them: flush number r is the r-th marked point.  One thread per
+    // flush (its word by bisection over the prefix counts, its bit by rank), so that the copies are independent loads
+    // and stores -- a thread walking the bits of its own words made a chain of dependent load -> store pairs
+    for (int r = threadIdx.x; r < nout; r += kPfSortThreads) {
+      int lo = 0, hi = nwords - 1;                             // last word with fpre <= r
+      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)fpre[mid] <= r) lo = mid; else hi = mid - 1; }
+      unsigned bits = fbits[lo];
+      for (int skip = r - (int)fpre[lo]; skip > 0; --skip) bits &= bits - 1u;
+      const int i = lo * 32 + __builtin_ctz(bits);
+      tmp[o0 + (unsigned long long)r] = sparse[o0 + (unsigned long long)i];
+    }
     __syncthreads();
     if (w == 0) {                                              // what is left, in slot order
       for (int h0 = 0; h0 < kPfSlots; h0 += 64) {

@@ -937,7 +937,7 @@ int ndt_prefilter_batch_dev(ndt_ctx *ctx, const float *raw_xy, size_t stride, co
   const int grid = B < 8 * ctx->num_cus ? B : 8 * ctx->num_cus;
   // scans of up to kPfSortMax points: ordered by slot, one thread per slot; longer ones: the step-by-step replay
   prefilter_sorted_kernel<<<grid, kPfSortThreads, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf,
-                                                           tmp, counts);
+                                                           sparse, tmp, counts);
   prefilter_mw_kernel<<<grid, 64 * kPfWaves, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf,
                                                       sparse, tmp, counts, NDT_PF_SORTED ? kPfSortMax : -1);
   prefilter_offsets_kernel<<<1, 1024, 0, st>>>(counts, B, (unsigned long long *)out_offsets);

@@ -3,11 +3,16 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from ndt_slam_amd import capi, synth
-B, npts = 256, 30000
+B = 256
 cfg = synth.CONFIGS["C3"]
 m = synth.make_map(cfg["n_map"], cfg["half"])
-sf = synth.ScanFactory(m, cfg["half"], npts)
-scans, off, _, _ = sf.batch(0, B)
+if len(sys.argv) > 1 and sys.argv[1] == "distinct":          # 30k distinct returns per scan: nearly every point flushes a voxel
+    scans, off, _, _ = synth.ScanFactory(m, cfg["half"], 30000).batch(0, B)
+else:                                                        # the bench's raw scans: every return three times, 4 mm of noise
+    s10, o10, _, _ = synth.ScanFactory(m, cfg["half"], cfg["n_scan"]).batch(0, B)
+    rng = np.random.default_rng(11)
+    scans = (np.repeat(s10, 3, axis=0) + rng.normal(0, 0.004, (3 * len(s10), 2)).astype(np.float32)).astype(np.float32)
+    off = o10.astype(np.int64) * 3
 dev = torch.device("cuda", 0)
 ctx = capi.Context(0)
 st = torch.cuda.Stream(device=dev); ctx.set_stream(st.cuda_stream)
