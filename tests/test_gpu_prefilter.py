@@ -26,7 +26,7 @@ def lidar_like(rng, n, radius=30.0):
 def test_prefilter_matches_oracle_bit_for_bit(gpu, oracle, leaf):
     capi, ctx = gpu
     rng = np.random.default_rng(7)
-    for n in (1, 2, 63, 64, 65, 360, 5000, 20000):
+    for n in (1, 2, 63, 64, 65, 360, 5000, 20000, 32768, 32769, 50000):    # up to 32768: by slot; above: step by step
         for cloud in (lidar_like(rng, n), rng.uniform(-40, 40, (n, 2)).astype(np.float32)):
             ref = oracle.approx_voxel_filter(cloud, leaf)
             got = ctx.prefilter(cloud, leaf)
@@ -40,6 +40,28 @@ def test_prefilter_scan_longer_than_the_flush_bitmap(gpu, oracle):
     rng = np.random.default_rng(17)
     cloud = lidar_like(rng, 300_000, radius=60.0)
     assert ctx.prefilter(cloud, 0.05).tobytes() == oracle.approx_voxel_filter(cloud, 0.05).tobytes()
+
+
+def test_prefilter_batch_of_mixed_lengths(gpu, oracle):
+    """One batch whose scans go down both kernels (by slot up to 32768 points, step by step above), empty scan included."""
+    import torch
+    capi, ctx = gpu
+    rng = np.random.default_rng(23)
+    lens = [100, 32768, 0, 40000, 30000, 1, 32769]
+    clouds = [lidar_like(rng, n) if n else np.zeros((0, 2), np.float32) for n in lens]
+    raw = np.concatenate(clouds).astype(np.float32)
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    dev = torch.device("cuda", 0)
+    d_raw = torch.from_numpy(raw).to(dev); d_off = torch.from_numpy(off).to(dev)
+    d_out = torch.empty_like(d_raw); d_ooff = torch.zeros(len(lens) + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    ctx.prefilter_batch_dev(d_raw.data_ptr(), 8, d_off.data_ptr(), len(lens), len(raw), 0.05, d_out.data_ptr(), d_ooff.data_ptr())
+    torch.cuda.synchronize()
+    ooff = d_ooff.cpu().numpy(); out = d_out.cpu().numpy()
+    for b, c in enumerate(clouds):
+        ref = oracle.approx_voxel_filter(c, 0.05) if len(c) else np.zeros((0, 2), np.float32)
+        got = out[int(ooff[b]):int(ooff[b + 1])]
+        assert got.shape == ref.shape and got.tobytes() == ref.tobytes(), b
 
 
 def test_prefilter_edge_cases(gpu, oracle):
