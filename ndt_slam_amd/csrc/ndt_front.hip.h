@@ -204,12 +204,13 @@ prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned 
 // other, its loads in flight ahead of it.  No lane ever waits for its turn on a slot, and every point is looked at by
 // one lane per pass instead of by each of eight waves.  A flush is parked at the index of the point that caused it and
 // marked in a bitmap in LDS; a prefix sum over the bitmap later, flush number r -- the r-th marked point: the order the
-// sequential filter emits them in -- is copied to its place by a thread of its own.  The slots left over follow in slot
+// sequential filter emits them in -- is divided by its count and copied to its place, every thread taking the flushes of
+// a run of bitmap words.  The slots left over follow in slot
 // order -- the reference's output, bit for bit (tests/test_gpu_prefilter.py).
 constexpr int kPfSortMax = 32768, kPfSortThreads = 512, kPfSortWaves = kPfSortThreads / 64;
 __global__ void __launch_bounds__(kPfSortThreads)
 prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
-                        float leaf, float2 *__restrict__ sparse /* at the raw offsets: flushes at the index of their cause */,
+                        float leaf, float4 *__restrict__ sparse /* at the raw offsets: flushes (sums, count) at the index of their cause */,
                         float2 *__restrict__ tmp /* at the raw offsets: dense result */, unsigned *__restrict__ counts) {
   __shared__ unsigned short order[kPfSortMax];                  // point numbers, ordered by slot, cloud order inside a slot
   __shared__ unsigned short wcount[kPfSortWaves][kPfSlots];      // pass 1: points of wave w's part in slot h; then: where they go
@@ -217,6 +218,7 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
   __shared__ PfSlot slot[kPfSlots];
   __shared__ unsigned fbits[kPfSortMax / 32];                   // point i causes a flush
   __shared__ unsigned short fpre[kPfSortMax / 32];              // marked points in front of word k
+  __shared__ unsigned long long same[kPfSortWaves][kPfSlots];   // per wave: lanes of the current step that hash to slot h
   __shared__ int wsum[kPfSortWaves + 1];
   static_assert(kPfSortThreads == kPfSlots, "one thread per slot");
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -228,7 +230,7 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
     const int n = (int)(offsets[b + 1] - o0);
     if (n > kPfSortMax || !NDT_PF_SORTED) continue;            // prefilter_mw_kernel's (uniform over the workgroup)
     __syncthreads();
-    for (int i = threadIdx.x; i < kPfSortWaves * kPfSlots; i += kPfSortThreads) (&wcount[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < kPfSortWaves * kPfSlots; i += kPfSortThreads) { (&wcount[0][0])[i] = 0; (&same[0][0])[i] = 0ull; }
     const int nwords = (n + 31) / 32;
     for (int i = threadIdx.x; i < nwords; i += kPfSortThreads) fbits[i] = 0u;
     __syncthreads();
@@ -239,14 +241,21 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
       const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
       return ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);
     };
-    // the lanes of a step that share a slot
+    // the lanes of a step that share a slot: every lane ORs its bit into the wave's mask word of its slot (an LDS atomic;
+    // lanes of one slot take turns in the LDS unit, a few of them in a scan a LiDAR made), reads the word back, and the
+    // first lane of every group clears it again.  (Nine ballots over the bits of the slot number -- what the step-by-step
+    // kernel does -- cost 70 instructions a step, most of them waiting on each other: 35 us a pass.)
     auto peers_of = [&](bool active, unsigned h) {
-      unsigned long long peers = __ballot(active);
-#pragma unroll
-      for (int bit = 0; bit < 9; ++bit) {
-        const unsigned long long one = __ballot(active && ((h >> bit) & 1u));
-        peers &= ((h >> bit) & 1u) ? one : ~one;
-      }
+      unsigned long long *word = &same[w][h];
+      if (active) atomicOr(word, 1ull << lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned long long peers = active ? *word : 0ull;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (active && (peers & lt) == 0ull) *word = 0ull;
       return peers;
     };
     // ---- pass 1: how many points of this wave's part fall into every slot
@@ -329,9 +338,9 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
         for (int u = 0; u < kWide; ++u) {
           if (k0 + u >= seg_e) break;
           const int ix = (int)floorf(p[u].x * inv), iy = (int)floorf(p[u].y * inv);
-          if (cnt && (ix != six || iy != siy)) {               // flush: parked at the index of the point that caused it
-            const int i = idx[u];
-            sparse[o0 + (unsigned long long)i] = make_float2(cx / (float)cnt, cy / (float)cnt);
+          if (cnt && (ix != six || iy != siy)) {               // flush: parked at the index of the point that caused it --
+            const int i = idx[u];                                // the sums and the count; the division is the copy's (a thread per
+            sparse[o0 + (unsigned long long)i] = make_float4(cx, cy, __int_as_float(cnt), 0.f);   // flush there, one lane after the other here)
             atomicOr(&fbits[i >> 5], 1u << (i & 31));
             cnt = 0; cx = 0.f; cy = 0.f;
           }
@@ -363,13 +372,32 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
     // ---- the flushes in the order of the points that caused them: flush number r is the r-th marked point.  One thread per
     // flush (its word by bisection over the prefix counts, its bit by rank), so that the copies are independent loads
     // and stores -- a thread walking the bits of its own words made a chain of dependent load -> store pairs
-    for (int r = threadIdx.x; r < nout; r += kPfSortThreads) {
-      int lo = 0, hi = nwords - 1;                             // last word with fpre <= r
-      while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)fpre[mid] <= r) lo = mid; else hi = mid - 1; }
-      unsigned bits = fbits[lo];
-      for (int skip = r - (int)fpre[lo]; skip > 0; --skip) bits &= bits - 1u;
-      const int i = lo * 32 + __builtin_ctz(bits);
-      tmp[o0 + (unsigned long long)r] = sparse[o0 + (unsigned long long)i];
+    // (a thread takes a run of consecutive words of the bitmap: the numbers of its flushes are consecutive, their sources
+    // the set bits in order; kCopy loads in flight, then the divisions -- the filter's `centroid / count` -- and the stores)
+    {
+      const int per = (nwords + kPfSortThreads - 1) / kPfSortThreads;
+      const int w0 = min((int)threadIdx.x * per, nwords), w1 = min(w0 + per, nwords);
+      constexpr int kCopy = 8;
+      int r = w0 < nwords ? (int)fpre[w0] : 0;
+      int k = w0;
+      unsigned bits = k < w1 ? fbits[k] : 0u;
+      for (int guard = 0; guard < 64 * 32 && k < w1; ++guard) {
+        int src[kCopy]; int got = 0;
+#pragma unroll
+        for (int u = 0; u < kCopy; ++u) {
+          while (!bits && k + 1 < w1) bits = fbits[++k];
+          src[u] = -1;
+          if (bits) { src[u] = k * 32 + __builtin_ctz(bits); bits &= bits - 1u; ++got; }
+        }
+        if (!got) break;
+        float4 v[kCopy];
+#pragma unroll
+        for (int u = 0; u < kCopy; ++u) if (src[u] >= 0) v[u] = sparse[o0 + (unsigned long long)src[u]];
+#pragma unroll
+        for (int u = 0; u < kCopy; ++u)
+          if (src[u] >= 0) tmp[o0 + (unsigned long long)(r + u)] = make_float2(v[u].x / (float)__float_as_int(v[u].z), v[u].y / (float)__float_as_int(v[u].z));
+        r += got;
+      }
     }
     __syncthreads();
     if (w == 0) {                                              // what is left, in slot order
