@@ -208,12 +208,14 @@ prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned 
 // a run of bitmap words.  The slots left over follow in slot
 // order -- the reference's output, bit for bit (tests/test_gpu_prefilter.py).
 constexpr int kPfSortMax = 32768, kPfSortThreads = 512, kPfSortWaves = kPfSortThreads / 64;
+constexpr int kPfTile = 8192;                                    // points of a scan staged in LDS at a time
 __global__ void __launch_bounds__(kPfSortThreads)
 prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
                         float leaf, float4 *__restrict__ sparse /* at the raw offsets: flushes (sums, count) at the index of their cause */,
                         float2 *__restrict__ tmp /* at the raw offsets: dense result */, unsigned *__restrict__ counts) {
-  __shared__ unsigned short order[kPfSortMax];                  // point numbers, ordered by slot, cloud order inside a slot
-  __shared__ unsigned short wcount[kPfSortWaves][kPfSlots];      // pass 1: points of wave w's part in slot h; then: where they go
+  __shared__ float2 pts[kPfTile];                               // the tile of the scan being worked on
+  __shared__ unsigned short order[kPfTile];                     // its point numbers (in the tile), ordered by slot, cloud order inside a slot
+  __shared__ unsigned short wcount[kPfSortWaves][kPfSlots];      // count: points of wave w's part in slot h; then: where they go
   __shared__ int sbase[kPfSlots + 1];                           // first position of slot h in `order`
   __shared__ PfSlot slot[kPfSlots];
   __shared__ unsigned fbits[kPfSortMax / 32];                   // point i causes a flush
@@ -224,19 +226,14 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const unsigned long long lt = (1ull << lane) - 1ull;
   const float inv = 1.0f / leaf;
-  constexpr int kAhead = 4;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const unsigned long long o0 = offsets[b];
     const int n = (int)(offsets[b + 1] - o0);
     if (n > kPfSortMax || !NDT_PF_SORTED) continue;            // prefilter_mw_kernel's (uniform over the workgroup)
     __syncthreads();
-    for (int i = threadIdx.x; i < kPfSortWaves * kPfSlots; i += kPfSortThreads) { (&wcount[0][0])[i] = 0; (&same[0][0])[i] = 0ull; }
+    for (int i = threadIdx.x; i < kPfSortWaves * kPfSlots; i += kPfSortThreads) (&same[0][0])[i] = 0ull;
     const int nwords = (n + 31) / 32;
     for (int i = threadIdx.x; i < nwords; i += kPfSortThreads) fbits[i] = 0u;
-    __syncthreads();
-    // ---- the part of the scan this wave counts and places: whole steps of 64 points
-    const int steps = (n + 63) / 64, spw = (steps + kPfSortWaves - 1) / kPfSortWaves;
-    const int s0 = min(w * spw, steps), s1 = min(s0 + spw, steps);
     auto slot_of = [&](float2 p) {
       const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
       return ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);
@@ -244,7 +241,7 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
     // the lanes of a step that share a slot: every lane ORs its bit into the wave's mask word of its slot (an LDS atomic;
     // lanes of one slot take turns in the LDS unit, a few of them in a scan a LiDAR made), reads the word back, and the
     // first lane of every group clears it again.  (Nine ballots over the bits of the slot number -- what the step-by-step
-    // kernel does -- cost 70 instructions a step, most of them waiting on each other: 35 us a pass.)
+    // kernel does -- cost 70 instructions a step, most of them waiting on each other: 35 us a pass against 18.)
     auto peers_of = [&](bool active, unsigned h) {
       unsigned long long *word = &same[w][h];
       if (active) atomicOr(word, 1ull << lane);
@@ -258,98 +255,77 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
       if (active && (peers & lt) == 0ull) *word = 0ull;
       return peers;
     };
-    // ---- pass 1: how many points of this wave's part fall into every slot
-    for (int sg = s0; sg < s1; sg += kAhead) {
-      float2 p[kAhead];
-#pragma unroll
-      for (int u = 0; u < kAhead; ++u) {
-        const int i = (sg + u) * 64 + lane;
-        p[u] = (sg + u < s1 && i < n) ? load_pt(xy, stride, (size_t)o0 + (size_t)i) : make_float2(0.f, 0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < kAhead; ++u) {
-        if (sg + u >= s1) break;
-        const int i = (sg + u) * 64 + lane;
-        const bool active = i < n;
-        const unsigned h = slot_of(p[u]);
-        const unsigned long long peers = peers_of(active, h);
-        if (active && (peers & lt) == 0ull) wcount[w][h] = (unsigned short)(wcount[w][h] + __builtin_popcountll(peers));   // first of its group
+    // slot h, this thread: its state lives in registers over the whole scan
+    const int h = threadIdx.x;
+    int six = 0, siy = 0, cnt = 0; float cx = 0.f, cy = 0.f;
+    for (int base = 0; base < n; base += kPfTile) {
+      const int m = min(kPfTile, n - base);
+      __syncthreads();                                         // the previous tile has been walked
+      // ---- the tile into LDS: the only time the scan is read (coalesced); everything below works from LDS
+      for (int i = threadIdx.x; i < m; i += kPfSortThreads) pts[i] = load_pt(xy, stride, (size_t)o0 + (size_t)(base + i));
+      for (int i = threadIdx.x; i < kPfSortWaves * kPfSlots; i += kPfSortThreads) (&wcount[0][0])[i] = 0;
+      __syncthreads();
+      // the part of the tile this wave counts and places: whole steps of 64 points
+      const int steps = (m + 63) / 64, spw = (steps + kPfSortWaves - 1) / kPfSortWaves;
+      const int s0 = min(w * spw, steps), s1 = min(s0 + spw, steps);
+      // ---- count: how many points of this wave's part fall into every slot
+      for (int sg = s0; sg < s1; ++sg) {
+        const int i = sg * 64 + lane;
+        const bool active = i < m;
+        const unsigned hh = slot_of(active ? pts[i] : make_float2(0.f, 0.f));
+        const unsigned long long peers = peers_of(active, hh);
+        if (active && (peers & lt) == 0ull) wcount[w][hh] = (unsigned short)(wcount[w][hh] + __builtin_popcountll(peers));   // first of its group
         __builtin_amdgcn_wave_barrier();
       }
-    }
-    __syncthreads();
-    // ---- slot h: its total, the offsets of the waves' shares inside it, then the exclusive scan of the totals
-    {
-      const int h = threadIdx.x;
-      int run = 0;
-#pragma unroll
-      for (int k = 0; k < kPfSortWaves; ++k) { const int c = wcount[k][h]; wcount[k][h] = (unsigned short)run; run += c; }
-      int incl = run;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-      if (lane == 63) wsum[w] = incl;
       __syncthreads();
-      int base = incl - run;
-      for (int k = 0; k < w; ++k) base += wsum[k];
-      sbase[h] = base;
-      if (h == kPfSlots - 1) sbase[kPfSlots] = base + run;
-    }
-    __syncthreads();
-    // ---- pass 2: every point's number to its place (slot base + the wave's offset in the slot + turn in the step)
-    for (int sg = s0; sg < s1; sg += kAhead) {
-      float2 p[kAhead];
+      // ---- slot h: its total in the tile, the offsets of the waves' shares inside it, the exclusive scan of the totals
+      {
+        int run = 0;
 #pragma unroll
-      for (int u = 0; u < kAhead; ++u) {
-        const int i = (sg + u) * 64 + lane;
-        p[u] = (sg + u < s1 && i < n) ? load_pt(xy, stride, (size_t)o0 + (size_t)i) : make_float2(0.f, 0.f);
+        for (int k = 0; k < kPfSortWaves; ++k) { const int c = wcount[k][h]; wcount[k][h] = (unsigned short)run; run += c; }
+        int incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int sb = incl - run;
+        for (int k = 0; k < w; ++k) sb += wsum[k];
+        sbase[h] = sb;
+        if (h == kPfSlots - 1) sbase[kPfSlots] = sb + run;
       }
-#pragma unroll
-      for (int u = 0; u < kAhead; ++u) {
-        if (sg + u >= s1) break;
-        const int i = (sg + u) * 64 + lane;
-        const bool active = i < n;
-        const unsigned h = slot_of(p[u]);
-        const unsigned long long peers = peers_of(active, h);
+      __syncthreads();
+      // ---- place: every point's number to its place (slot base + the wave's offset in the slot + turn in the step)
+      for (int sg = s0; sg < s1; ++sg) {
+        const int i = sg * 64 + lane;
+        const bool active = i < m;
+        const unsigned hh = slot_of(active ? pts[i] : make_float2(0.f, 0.f));
+        const unsigned long long peers = peers_of(active, hh);
         const int turn = __builtin_popcountll(peers & lt);
         int at = 0;
-        if (active) at = sbase[h] + wcount[w][h];
+        if (active) at = sbase[hh] + wcount[w][hh];
         __builtin_amdgcn_wave_barrier();                       // all lanes of the group have read the wave's offset
         if (active) {
           order[at + turn] = (unsigned short)i;
-          if (turn == 0) wcount[w][h] = (unsigned short)(wcount[w][h] + __builtin_popcountll(peers));
+          if (turn == 0) wcount[w][hh] = (unsigned short)(wcount[w][hh] + __builtin_popcountll(peers));
         }
         __builtin_amdgcn_wave_barrier();
       }
-    }
-    __syncthreads();
-    // ---- slot h, one thread: its points in cloud order.  mark: only note which points cause a flush; else: write the flushes
-    const int h = threadIdx.x;
-    const int seg_a = sbase[h], seg_e = sbase[h + 1];
-    {
-      int six = 0, siy = 0, cnt = 0; float cx = 0.f, cy = 0.f;
-      constexpr int kWide = 8;
-      for (int k0 = seg_a; k0 < seg_e; k0 += kWide) {
-        int idx[kWide]; float2 p[kWide];
-#pragma unroll
-        for (int u = 0; u < kWide; ++u) idx[u] = order[min(k0 + u, seg_e - 1)];
-#pragma unroll
-        for (int u = 0; u < kWide; ++u) p[u] = load_pt(xy, stride, (size_t)o0 + (size_t)idx[u]);
-#pragma unroll
-        for (int u = 0; u < kWide; ++u) {
-          if (k0 + u >= seg_e) break;
-          const int ix = (int)floorf(p[u].x * inv), iy = (int)floorf(p[u].y * inv);
-          if (cnt && (ix != six || iy != siy)) {               // flush: parked at the index of the point that caused it --
-            const int i = idx[u];                                // the sums and the count; the division is the copy's (a thread per
-            sparse[o0 + (unsigned long long)i] = make_float4(cx, cy, __int_as_float(cnt), 0.f);   // flush there, one lane after the other here)
-            atomicOr(&fbits[i >> 5], 1u << (i & 31));
-            cnt = 0; cx = 0.f; cy = 0.f;
-          }
-          six = ix; siy = iy; cnt += 1; cx += p[u].x; cy += p[u].y;
+      __syncthreads();
+      // ---- slot h, one thread: its points of the tile in cloud order, from LDS
+      for (int k = sbase[h]; k < sbase[h + 1]; ++k) {
+        const int li = order[k];
+        const float2 p = pts[li];
+        const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
+        if (cnt && (ix != six || iy != siy)) {                 // flush: parked at the index of the point that caused it --
+          const int i = base + li;                             // the sums and the count; the division is the copy's (a thread per
+          sparse[o0 + (unsigned long long)i] = make_float4(cx, cy, __int_as_float(cnt), 0.f);   // flush there, one lane after the other here)
+          atomicOr(&fbits[i >> 5], 1u << (i & 31));
+          cnt = 0; cx = 0.f; cy = 0.f;
         }
+        six = ix; siy = iy; cnt += 1; cx += p.x; cy += p.y;
       }
-      PfSlot z; z.ix = six; z.iy = siy; z.cnt = cnt; z.cx = cx; z.cy = cy; z.pad = 0;
-      slot[h] = z;
     }
+    { PfSlot z; z.ix = six; z.iy = siy; z.cnt = cnt; z.cx = cx; z.cy = cy; z.pad = 0; slot[h] = z; }
     __syncthreads();
     // ---- marked points in front of every word of the bitmap
     int nout = 0;
@@ -361,7 +337,7 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
       int incl = mine_cnt;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-      if (lane == 63) wsum[w] = incl;                          // (the slot scan's use of wsum ended two barriers ago)
+      if (lane == 63) wsum[w] = incl;
       __syncthreads();
       int off = incl - mine_cnt;
       for (int k = 0; k < w; ++k) off += wsum[k];
@@ -369,9 +345,7 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
       for (int k = w0; k < w1; ++k) { fpre[k] = (unsigned short)off; off += __builtin_popcount(fbits[k]); }
     }
     __syncthreads();
-    // ---- the flushes in the order of the points that caused them: flush number r is the r-th marked point.  One thread per
-    // flush (its word by bisection over the prefix counts, its bit by rank), so that the copies are independent loads
-    // and stores -- a thread walking the bits of its own words made a chain of dependent load -> store pairs
+    // ---- the flushes in the order of the points that caused them: flush number r is the r-th marked point
     // (a thread takes a run of consecutive words of the bitmap: the numbers of its flushes are consecutive, their sources
     // the set bits in order; kCopy loads in flight, then the divisions -- the filter's `centroid / count` -- and the stores)
     {
