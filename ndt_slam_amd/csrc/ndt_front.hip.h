@@ -202,24 +202,25 @@ prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned 
 // the points of its own contiguous part of the scan, step by step in cloud order, a lane's turn among equal slots inside
 // a step from ballots -- and then thread h walks the points of slot h with the slot's state in registers, one after the
 // other, its loads in flight ahead of it.  No lane ever waits for its turn on a slot, and every point is looked at by
-// one lane per pass instead of by each of eight waves.  A flush is parked at the index of the point that caused it and
-// marked in a bitmap in LDS; a prefix sum over the bitmap later, flush number r -- the r-th marked point: the order the
-// sequential filter emits them in -- is divided by its count and copied to its place, every thread taking the flushes of
-// a run of bitmap words.  The slots left over follow in slot
+// one lane per pass instead of by each of eight waves.  The scan goes through LDS in tiles of kPfTile points (read once,
+// coalesced); a flush is parked in LDS in the place of the point that caused it and marked in the tile's bitmap; a
+// prefix sum over the bitmap later, the flushes of the tile -- the r-th marked point is flush number r: the order the
+// sequential filter emits them in -- are divided by their counts and stored.  The slots left over follow in slot
 // order -- the reference's output, bit for bit (tests/test_gpu_prefilter.py).
 constexpr int kPfSortMax = 32768, kPfSortThreads = 512, kPfSortWaves = kPfSortThreads / 64;
 constexpr int kPfTile = 8192;                                    // points of a scan staged in LDS at a time
 __global__ void __launch_bounds__(kPfSortThreads)
 prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
-                        float leaf, float4 *__restrict__ sparse /* at the raw offsets: flushes (sums, count) at the index of their cause */,
-                        float2 *__restrict__ tmp /* at the raw offsets: dense result */, unsigned *__restrict__ counts) {
+                        float leaf, float2 *__restrict__ tmp /* at the raw offsets: dense result */,
+                        unsigned *__restrict__ counts) {
   __shared__ float2 pts[kPfTile];                               // the tile of the scan being worked on
   __shared__ unsigned short order[kPfTile];                     // its point numbers (in the tile), ordered by slot, cloud order inside a slot
   __shared__ unsigned short wcount[kPfSortWaves][kPfSlots];      // count: points of wave w's part in slot h; then: where they go
   __shared__ int sbase[kPfSlots + 1];                           // first position of slot h in `order`
   __shared__ PfSlot slot[kPfSlots];
-  __shared__ unsigned fbits[kPfSortMax / 32];                   // point i causes a flush
-  __shared__ unsigned short fpre[kPfSortMax / 32];              // marked points in front of word k
+  __shared__ unsigned short fcount[kPfTile];                    // flush parked at point i of the tile: points of the voxel it closes
+  __shared__ unsigned fbits[kPfTile / 32];                      // point i of the tile causes a flush
+  __shared__ unsigned short fpre[kPfTile / 32];                 // marked points of the tile in front of word k
   __shared__ unsigned long long same[kPfSortWaves][kPfSlots];   // per wave: lanes of the current step that hash to slot h
   __shared__ int wsum[kPfSortWaves + 1];
   static_assert(kPfSortThreads == kPfSlots, "one thread per slot");
@@ -232,8 +233,6 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
     if (n > kPfSortMax || !NDT_PF_SORTED) continue;            // prefilter_mw_kernel's (uniform over the workgroup)
     __syncthreads();
     for (int i = threadIdx.x; i < kPfSortWaves * kPfSlots; i += kPfSortThreads) (&same[0][0])[i] = 0ull;
-    const int nwords = (n + 31) / 32;
-    for (int i = threadIdx.x; i < nwords; i += kPfSortThreads) fbits[i] = 0u;
     auto slot_of = [&](float2 p) {
       const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
       return ((unsigned)ix * 7171u + (unsigned)iy * 3079u) & (unsigned)(kPfSlots - 1);
@@ -258,12 +257,14 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
     // slot h, this thread: its state lives in registers over the whole scan
     const int h = threadIdx.x;
     int six = 0, siy = 0, cnt = 0; float cx = 0.f, cy = 0.f;
+    int nout = 0;                                              // flushes written so far (uniform)
     for (int base = 0; base < n; base += kPfTile) {
       const int m = min(kPfTile, n - base);
       __syncthreads();                                         // the previous tile has been walked
       // ---- the tile into LDS: the only time the scan is read (coalesced); everything below works from LDS
       for (int i = threadIdx.x; i < m; i += kPfSortThreads) pts[i] = load_pt(xy, stride, (size_t)o0 + (size_t)(base + i));
       for (int i = threadIdx.x; i < kPfSortWaves * kPfSlots; i += kPfSortThreads) (&wcount[0][0])[i] = 0;
+      for (int i = threadIdx.x; i < kPfTile / 32; i += kPfSortThreads) fbits[i] = 0u;
       __syncthreads();
       // the part of the tile this wave counts and places: whole steps of 64 points
       const int steps = (m + 63) / 64, spw = (steps + kPfSortWaves - 1) / kPfSortWaves;
@@ -311,68 +312,49 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
         __builtin_amdgcn_wave_barrier();
       }
       __syncthreads();
-      // ---- slot h, one thread: its points of the tile in cloud order, from LDS
+      // ---- slot h, one thread: its points of the tile in cloud order, from LDS.  A flush is parked in the place of the
+      // point that caused it (the point has been read: its place is free) -- the sums, and the count beside it; the
+      // division is the copy's, a thread per run of flushes there, one lane after the other here
       for (int k = sbase[h]; k < sbase[h + 1]; ++k) {
         const int li = order[k];
         const float2 p = pts[li];
         const int ix = (int)floorf(p.x * inv), iy = (int)floorf(p.y * inv);
-        if (cnt && (ix != six || iy != siy)) {                 // flush: parked at the index of the point that caused it --
-          const int i = base + li;                             // the sums and the count; the division is the copy's (a thread per
-          sparse[o0 + (unsigned long long)i] = make_float4(cx, cy, __int_as_float(cnt), 0.f);   // flush there, one lane after the other here)
-          atomicOr(&fbits[i >> 5], 1u << (i & 31));
+        if (cnt && (ix != six || iy != siy)) {
+          pts[li] = make_float2(cx, cy);
+          fcount[li] = (unsigned short)cnt;
+          atomicOr(&fbits[li >> 5], 1u << (li & 31));
           cnt = 0; cx = 0.f; cy = 0.f;
         }
         six = ix; siy = iy; cnt += 1; cx += p.x; cy += p.y;
       }
-    }
-    { PfSlot z; z.ix = six; z.iy = siy; z.cnt = cnt; z.cx = cx; z.cy = cy; z.pad = 0; slot[h] = z; }
-    __syncthreads();
-    // ---- marked points in front of every word of the bitmap
-    int nout = 0;
-    {
-      int mine_cnt = 0;
-      const int per = (nwords + kPfSortThreads - 1) / kPfSortThreads;
-      const int w0 = min((int)threadIdx.x * per, nwords), w1 = min(w0 + per, nwords);
-      for (int k = w0; k < w1; ++k) mine_cnt += __builtin_popcount(fbits[k]);
-      int incl = mine_cnt;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-      if (lane == 63) wsum[w] = incl;
       __syncthreads();
-      int off = incl - mine_cnt;
-      for (int k = 0; k < w; ++k) off += wsum[k];
-      for (int k = 0; k < kPfSortWaves; ++k) nout += wsum[k];
-      for (int k = w0; k < w1; ++k) { fpre[k] = (unsigned short)off; off += __builtin_popcount(fbits[k]); }
-    }
-    __syncthreads();
-    // ---- the flushes in the order of the points that caused them: flush number r is the r-th marked point
-    // (a thread takes a run of consecutive words of the bitmap: the numbers of its flushes are consecutive, their sources
-    // the set bits in order; kCopy loads in flight, then the divisions -- the filter's `centroid / count` -- and the stores)
-    {
-      const int per = (nwords + kPfSortThreads - 1) / kPfSortThreads;
-      const int w0 = min((int)threadIdx.x * per, nwords), w1 = min(w0 + per, nwords);
-      constexpr int kCopy = 8;
-      int r = w0 < nwords ? (int)fpre[w0] : 0;
-      int k = w0;
-      unsigned bits = k < w1 ? fbits[k] : 0u;
-      for (int guard = 0; guard < 64 * 32 && k < w1; ++guard) {
-        int src[kCopy]; int got = 0;
+      // ---- the flushes of the tile in the order of the points that caused them (every flush of this tile comes before
+      // every flush of the next): prefix sum over the tile's bitmap, then thread t divides and stores the flushes of word t
+      {
+        const int twords = (m + 31) / 32;                      // <= 256
+        const int mine = (int)threadIdx.x < twords ? __builtin_popcount(fbits[threadIdx.x]) : 0;
+        int incl = mine;
 #pragma unroll
-        for (int u = 0; u < kCopy; ++u) {
-          while (!bits && k + 1 < w1) bits = fbits[++k];
-          src[u] = -1;
-          if (bits) { src[u] = k * 32 + __builtin_ctz(bits); bits &= bits - 1u; ++got; }
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int r = nout + incl - mine;
+        for (int k = 0; k < w; ++k) r += wsum[k];
+        int tile_total = 0;
+        for (int k = 0; k < kPfSortWaves; ++k) tile_total += wsum[k];
+        if ((int)threadIdx.x < twords) {
+          unsigned bits = fbits[threadIdx.x];
+          while (bits) {
+            const int li = (int)threadIdx.x * 32 + __builtin_ctz(bits); bits &= bits - 1u;
+            const float2 sum = pts[li]; const float c = (float)fcount[li];
+            tmp[o0 + (unsigned long long)r] = make_float2(sum.x / c, sum.y / c);
+            ++r;
+          }
         }
-        if (!got) break;
-        float4 v[kCopy];
-#pragma unroll
-        for (int u = 0; u < kCopy; ++u) if (src[u] >= 0) v[u] = sparse[o0 + (unsigned long long)src[u]];
-#pragma unroll
-        for (int u = 0; u < kCopy; ++u)
-          if (src[u] >= 0) tmp[o0 + (unsigned long long)(r + u)] = make_float2(v[u].x / (float)__float_as_int(v[u].z), v[u].y / (float)__float_as_int(v[u].z));
-        r += got;
+        nout += tile_total;
       }
     }
+    { PfSlot z; z.ix = six; z.iy = siy; z.cnt = cnt; z.cx = cx; z.cy = cy; z.pad = 0; slot[h] = z; }
     __syncthreads();
     if (w == 0) {                                              // what is left, in slot order
       for (int h0 = 0; h0 < kPfSlots; h0 += 64) {

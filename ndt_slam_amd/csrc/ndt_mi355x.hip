@@ -930,14 +930,14 @@ int ndt_prefilter_batch_dev(ndt_ctx *ctx, const float *raw_xy, size_t stride, co
   if ((rc = scratch_begin(ctx, st))) return rc;
   // filtered points at the raw offsets, then the per-scan counts
   const size_t tmp_bytes = total_raw_points * sizeof(float2);
-  if ((rc = ensure(ctx, &ctx->d_pf, &ctx->d_pf_cap, 3 * tmp_bytes + (size_t)B * sizeof(unsigned)))) return rc;
+  if ((rc = ensure(ctx, &ctx->d_pf, &ctx->d_pf_cap, 2 * tmp_bytes + (size_t)B * sizeof(unsigned)))) return rc;
   float2 *tmp = (float2 *)ctx->d_pf;                                   // dense result at the raw offsets
-  float2 *sparse = (float2 *)((char *)ctx->d_pf + tmp_bytes);          // flushes at the index of their cause (16 bytes a point: sums + count)
-  unsigned *counts = (unsigned *)((char *)ctx->d_pf + 3 * tmp_bytes);
+  float2 *sparse = (float2 *)((char *)ctx->d_pf + tmp_bytes);          // step-by-step kernel: flushes at the index of their cause
+  unsigned *counts = (unsigned *)((char *)ctx->d_pf + 2 * tmp_bytes);
   const int grid = B < 8 * ctx->num_cus ? B : 8 * ctx->num_cus;
   // scans of up to kPfSortMax points: ordered by slot, one thread per slot; longer ones: the step-by-step replay
   prefilter_sorted_kernel<<<grid, kPfSortThreads, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf,
-                                                           (float4 *)sparse, tmp, counts);
+                                                           tmp, counts);
   prefilter_mw_kernel<<<grid, 64 * kPfWaves, 0, st>>>(raw_xy, stride, (const unsigned long long *)raw_offsets, B, leaf,
                                                       sparse, tmp, counts, NDT_PF_SORTED ? kPfSortMax : -1);
   prefilter_offsets_kernel<<<1, 1024, 0, st>>>(counts, B, (unsigned long long *)out_offsets);
