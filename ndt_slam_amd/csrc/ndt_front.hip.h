@@ -209,6 +209,7 @@ prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned 
 // order -- the reference's output, bit for bit (tests/test_gpu_prefilter.py).
 constexpr int kPfSortMax = 32768, kPfSortThreads = 512, kPfSortWaves = kPfSortThreads / 64;
 constexpr int kPfTile = 8192;                                    // points of a scan staged in LDS at a time
+constexpr int kPfStepsPerWave = kPfTile / 64 / kPfSortWaves;      // steps of 64 points a wave counts and places in a tile
 __global__ void __launch_bounds__(kPfSortThreads)
 prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsigned long long *__restrict__ offsets, int B,
                         float leaf, float2 *__restrict__ tmp /* at the raw offsets: dense result */,
@@ -258,25 +259,51 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
     const int h = threadIdx.x;
     int six = 0, siy = 0, cnt = 0; float cx = 0.f, cy = 0.f;
     int nout = 0;                                              // flushes written so far (uniform)
+    constexpr int kPfPerThread = kPfTile / kPfSortThreads;      // points of a tile a thread brings in
+    float2 ahead[kPfPerThread];                                // the next tile, in flight while this one is worked on
+#pragma unroll
+    for (int u = 0; u < kPfPerThread; ++u) {
+      const int i = (int)threadIdx.x + u * kPfSortThreads;
+      ahead[u] = i < n ? load_pt(xy, stride, (size_t)o0 + (size_t)i) : make_float2(0.f, 0.f);
+    }
     for (int base = 0; base < n; base += kPfTile) {
       const int m = min(kPfTile, n - base);
       __syncthreads();                                         // the previous tile has been walked
       // ---- the tile into LDS: the only time the scan is read (coalesced); everything below works from LDS
-      for (int i = threadIdx.x; i < m; i += kPfSortThreads) pts[i] = load_pt(xy, stride, (size_t)o0 + (size_t)(base + i));
+#pragma unroll
+      for (int u = 0; u < kPfPerThread; ++u) {
+        const int i = (int)threadIdx.x + u * kPfSortThreads;
+        if (i < m) pts[i] = ahead[u];
+      }
+#pragma unroll
+      for (int u = 0; u < kPfPerThread; ++u) {
+        const int i = base + kPfTile + (int)threadIdx.x + u * kPfSortThreads;
+        ahead[u] = i < n ? load_pt(xy, stride, (size_t)o0 + (size_t)i) : make_float2(0.f, 0.f);
+      }
       for (int i = threadIdx.x; i < kPfSortWaves * kPfSlots; i += kPfSortThreads) (&wcount[0][0])[i] = 0;
       for (int i = threadIdx.x; i < kPfTile / 32; i += kPfSortThreads) fbits[i] = 0u;
       __syncthreads();
       // the part of the tile this wave counts and places: whole steps of 64 points
       const int steps = (m + 63) / 64, spw = (steps + kPfSortWaves - 1) / kPfSortWaves;
       const int s0 = min(w * spw, steps), s1 = min(s0 + spw, steps);
-      // ---- count: how many points of this wave's part fall into every slot
-      for (int sg = s0; sg < s1; ++sg) {
-        const int i = sg * 64 + lane;
-        const bool active = i < m;
-        const unsigned hh = slot_of(active ? pts[i] : make_float2(0.f, 0.f));
-        const unsigned long long peers = peers_of(active, hh);
-        if (active && (peers & lt) == 0ull) wcount[w][hh] = (unsigned short)(wcount[w][hh] + __builtin_popcountll(peers));   // first of its group
-        __builtin_amdgcn_wave_barrier();
+      // ---- count: how many points of this wave's part fall into every slot.  What a lane learns about its point here --
+      // slot, turn among the lanes of the step with the same slot, size of that group -- is kept in a register per step
+      // for the placing pass (which then needs no second look at the mask words)
+      unsigned memo[kPfStepsPerWave];
+#pragma unroll
+      for (int j = 0; j < kPfStepsPerWave; ++j) {
+        const int sg = s0 + j;
+        memo[j] = 0xFFFFFFFFu;
+        if (sg < s1) {                                         // (uniform over the wave)
+          const int i = sg * 64 + lane;
+          const bool active = i < m;
+          const unsigned hh = slot_of(active ? pts[i] : make_float2(0.f, 0.f));
+          const unsigned long long peers = peers_of(active, hh);
+          const unsigned turn = (unsigned)__builtin_popcountll(peers & lt), size = (unsigned)__builtin_popcountll(peers);
+          if (active && turn == 0u) wcount[w][hh] = (unsigned short)(wcount[w][hh] + size);   // first of its group
+          if (active) memo[j] = hh | (turn << 9) | (size << 16);
+          __builtin_amdgcn_wave_barrier();
+        }
       }
       __syncthreads();
       // ---- slot h: its total in the tile, the offsets of the waves' shares inside it, the exclusive scan of the totals
@@ -296,20 +323,21 @@ prefilter_sorted_kernel(const float *__restrict__ xy, size_t stride, const unsig
       }
       __syncthreads();
       // ---- place: every point's number to its place (slot base + the wave's offset in the slot + turn in the step)
-      for (int sg = s0; sg < s1; ++sg) {
-        const int i = sg * 64 + lane;
-        const bool active = i < m;
-        const unsigned hh = slot_of(active ? pts[i] : make_float2(0.f, 0.f));
-        const unsigned long long peers = peers_of(active, hh);
-        const int turn = __builtin_popcountll(peers & lt);
-        int at = 0;
-        if (active) at = sbase[hh] + wcount[w][hh];
-        __builtin_amdgcn_wave_barrier();                       // all lanes of the group have read the wave's offset
-        if (active) {
-          order[at + turn] = (unsigned short)i;
-          if (turn == 0) wcount[w][hh] = (unsigned short)(wcount[w][hh] + __builtin_popcountll(peers));
+#pragma unroll
+      for (int j = 0; j < kPfStepsPerWave; ++j) {
+        const int sg = s0 + j;
+        if (sg < s1) {                                         // (uniform over the wave)
+          const bool active = memo[j] != 0xFFFFFFFFu;
+          const unsigned hh = memo[j] & 511u, turn = (memo[j] >> 9) & 127u, size = memo[j] >> 16;
+          int at = 0;
+          if (active) at = sbase[hh] + wcount[w][hh];
+          __builtin_amdgcn_wave_barrier();                     // all lanes of the group have read the wave's offset
+          if (active) {
+            order[at + (int)turn] = (unsigned short)(sg * 64 + lane);
+            if (turn == 0u) wcount[w][hh] = (unsigned short)(wcount[w][hh] + size);
+          }
+          __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
       }
       __syncthreads();
       // ---- slot h, one thread: its points of the tile in cloud order, from LDS.  A flush is parked in the place of the
