@@ -207,7 +207,8 @@ prefilter_mw_kernel(const float *__restrict__ xy, size_t stride, const unsigned 
 // prefix sum over the bitmap later, the flushes of the tile -- the r-th marked point is flush number r: the order the
 // sequential filter emits them in -- are divided by their counts and stored.  The slots left over follow in slot
 // order -- the reference's output, bit for bit (tests/test_gpu_prefilter.py).
-constexpr int kPfSortMax = 32768, kPfSortThreads = 512, kPfSortWaves = kPfSortThreads / 64;
+constexpr int kPfSortMax = 65535;      // the count of a voxel's points travels as 16 bits (fcount): a scan must not have more
+constexpr int kPfSortThreads = 512, kPfSortWaves = kPfSortThreads / 64;
 constexpr int kPfTile = 8192;                                    // points of a scan staged in LDS at a time
 constexpr int kPfStepsPerWave = kPfTile / 64 / kPfSortWaves;      // steps of 64 points a wave counts and places in a tile
 __global__ void __launch_bounds__(kPfSortThreads)

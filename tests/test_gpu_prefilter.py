@@ -26,7 +26,7 @@ def lidar_like(rng, n, radius=30.0):
 def test_prefilter_matches_oracle_bit_for_bit(gpu, oracle, leaf):
     capi, ctx = gpu
     rng = np.random.default_rng(7)
-    for n in (1, 2, 63, 64, 65, 360, 5000, 20000, 32768, 32769, 50000):    # up to 32768: by slot; above: step by step
+    for n in (1, 2, 63, 64, 65, 360, 5000, 8192, 8193, 20000, 50000, 65535, 65536):    # up to 65535: by slot (tiles of 8192); above: step by step
         for cloud in (lidar_like(rng, n), rng.uniform(-40, 40, (n, 2)).astype(np.float32)):
             ref = oracle.approx_voxel_filter(cloud, leaf)
             got = ctx.prefilter(cloud, leaf)
@@ -43,11 +43,11 @@ def test_prefilter_scan_longer_than_the_flush_bitmap(gpu, oracle):
 
 
 def test_prefilter_batch_of_mixed_lengths(gpu, oracle):
-    """One batch whose scans go down both kernels (by slot up to 32768 points, step by step above), empty scan included."""
+    """One batch whose scans go down both kernels (by slot up to 65535 points, step by step above), empty scan included."""
     import torch
     capi, ctx = gpu
     rng = np.random.default_rng(23)
-    lens = [100, 32768, 0, 40000, 30000, 1, 32769]
+    lens = [100, 65535, 0, 70000, 30000, 1, 65536, 8192]
     clouds = [lidar_like(rng, n) if n else np.zeros((0, 2), np.float32) for n in lens]
     raw = np.concatenate(clouds).astype(np.float32)
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
