@@ -73,7 +73,7 @@ __device__ __forceinline__ void solve3(const double Hs[6], double b0, double b1,
 }
 
 // More-Thuente trial value, cases 1-4 (Sun & Yuan 2.4.2 / 2.4.5 / 2.4.52 / 2.4.56).
-__device__ __noinline__ double mt_trial(double a_l, double f_l, double g_l, double a_u, double f_u,
+__device__ __forceinline__ double mt_trial(double a_l, double f_l, double g_l, double a_u, double f_u,
                                         double g_u, double a_t, double f_t, double g_t) {
   if (f_t > f_l) {
     double z = 3 * (f_t - f_l) / (a_t - a_l) - g_t - g_l;
@@ -165,17 +165,23 @@ __device__ __noinline__ void begin_outer(AlignState &S, const OptParams &P) {
   }
 }
 
-// Consume one derivative pass (score, gradient, Hessian at the current trial transform).
-__device__ __noinline__ void advance(AlignState &S, const OptParams &P, const MapView &M,
-                                     const double tot[kAcc], double *trace, int trace_cap,
-                                     int *trace_rows) {
-  const double w = M.d1 * M.d2;
-  S.score = -M.d1 * tot[0];
-  S.g[0] = w * tot[1]; S.g[1] = w * tot[2]; S.g[2] = w * tot[3];
-  S.H[0] = w * tot[4]; S.H[1] = w * tot[5]; S.H[2] = w * tot[6];
-  S.H[3] = w * tot[7]; S.H[4] = w * tot[8]; S.H[5] = w * tot[9];
-  S.pairs += tot[10];
-  S.evals++; S.ref_evals++;
+// Consume one derivative pass (score, gradient, Hessian at the current trial transform).  Three leaf functions, called
+// one after the other by lane 0 of the owning workgroup: a function that calls another keeps its live values in
+// callee-saved registers, which it has to save and reload through scratch memory on every call -- half a microsecond
+// on the critical path of every pass.  Leaves that stay inside the caller-saved registers touch no scratch at all.
+__device__ __noinline__ void advance_totals(AlignState &S, const MapView &M, const double tot[kAcc], double *trace,
+                                            int trace_cap, int *trace_rows) {
+  // (all loads first: S and tot are both LDS, and a store to S would otherwise fence the loads behind it)
+  const double d1 = M.d1, w = d1 * M.d2;
+  const double t0 = tot[0], t1 = tot[1], t2 = tot[2], t3 = tot[3], t4 = tot[4], t5 = tot[5], t6 = tot[6], t7 = tot[7],
+               t8 = tot[8], t9 = tot[9], t10 = tot[10], pr = S.pairs;
+  const int ev = S.evals, rev = S.ref_evals;
+  S.score = -d1 * t0;
+  S.g[0] = w * t1; S.g[1] = w * t2; S.g[2] = w * t3;
+  S.H[0] = w * t4; S.H[1] = w * t5; S.H[2] = w * t6;
+  S.H[3] = w * t7; S.H[4] = w * t8; S.H[5] = w * t9;
+  S.pairs = pr + t10;
+  S.evals = ev + 1; S.ref_evals = rev + 1;
   if (trace) {
     int row = *trace_rows;
     if (row < trace_cap) {
@@ -186,7 +192,11 @@ __device__ __noinline__ void advance(AlignState &S, const OptParams &P, const Ma
     }
     *trace_rows = row + 1;
   }
-  if (S.phase == PH_INIT) { begin_outer(S, P); return; }
+}
+
+// The line search's turn after a pass.  Returns true when an outer iteration has to be started (begin_outer).
+__device__ __noinline__ bool advance_step(AlignState &S, const OptParams &P) {
+  if (S.phase == PH_INIT) return true;
 
   const double mu = P.mt_mu, nu = P.mt_nu;
   double phi_t = -S.score;
@@ -214,7 +224,7 @@ __device__ __noinline__ void advance(AlignState &S, const OptParams &P, const Ma
     S.a_t = a_t;
     set_trial(S, P, false);
     S.phase = PH_LS_INNER;
-    return;
+    return false;
   }
   // line search done.  The reference now runs a Hessian-only pass when the inner loop ran;
   // the Hessian of the last pass (same cloud, same angle terms) is that Hessian already.
@@ -224,8 +234,15 @@ __device__ __noinline__ void advance(AlignState &S, const OptParams &P, const Ma
   int over = P.conv_ge ? (S.iters >= P.max_iter) : (S.iters > P.max_iter);
   bool conv = over || (S.iters && (fabs(a) < P.trans_eps));
   S.iters++;
-  if (conv) { S.converged = 1; S.phase = PH_DONE; return; }
-  begin_outer(S, P);
+  if (conv) { S.converged = 1; S.phase = PH_DONE; return false; }
+  return true;
+}
+
+__device__ __forceinline__ void advance(AlignState &S, const OptParams &P, const MapView &M,
+                                        const double tot[kAcc], double *trace, int trace_cap,
+                                        int *trace_rows) {
+  advance_totals(S, M, tot, trace, trace_cap, trace_rows);
+  if (advance_step(S, P)) begin_outer(S, P);
 }
 
 __device__ __noinline__ void init_state(AlignState &S, const OptParams &P, const double init[3],
