@@ -16,6 +16,7 @@
 // point fails with NDT_E_NO_DEVICE: there is no CPU fallback.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -227,17 +228,17 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   // one workgroup per CU (the LDS window allows no more); idle workgroups help unfinished scans
   const int ncu = ctx->workgroups > 0 ? ctx->workgroups : ctx->num_cus;
   const int grid = helpers ? ncu : (B < ncu ? B : ncu);
+  // timing: the events ride on the kernels' own dispatch packets (hipExtLaunchKernelGGL: start / stop of that kernel) -- an
+  // event RECORD is a packet of its own between two kernels, three of them per launch cost the stream 6-10 us
   hipEvent_t *evr = ctx->ev_ring + 3 * (ctx->launches % ndt_ctx::kTimeRing);
-  HIP_TRY(ctx, hipEventRecord(evr[0], st));
-#define NDT_LAUNCH(S_, I_)                                                                           \
-  ndt_align_kernel<S_, I_><<<grid, kBlock, 0, st>>>(V, O, scans, offsets, B, shared_scan, inits, out, trace, \
-                                                    trace_cap, trace_rows, sorted, ws, helpers, prof)
+#define NDT_LAUNCH(S_, I_)                                                                                          \
+  hipExtLaunchKernelGGL((ndt_align_kernel<S_, I_>), dim3(grid), dim3(kBlock), 0, st, evr[0], evr[1], 0, V, O, scans, \
+                        offsets, B, shared_scan, inits, out, trace, trace_cap, trace_rows, sorted, ws, helpers, prof)
   if (sse && incl) NDT_LAUNCH(true, true);
   else if (sse)    NDT_LAUNCH(true, false);
   else if (incl)   NDT_LAUNCH(false, true);
   else             NDT_LAUNCH(false, false);
 #undef NDT_LAUNCH
-  HIP_TRY(ctx, hipEventRecord(evr[1], st));
   // a7: fitness scores, behind the matches on the same stream
   {
     const size_t avg = shared_scan ? total_points : (total_points + (size_t)B - 1) / (size_t)B;
@@ -245,10 +246,9 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
     const dim3 grid(gx, (unsigned)std::min(B, 65535));
     if (sse) fitness_points_kernel<true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit);
     else     fitness_points_kernel<false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit);
-    fitness_reduce_kernel<<<std::min(B, 4 * ctx->num_cus), kFitBlock, 0, st>>>(offsets, B, shared_scan, fit, out,
-                                                                                (uint4 *)ws, (unsigned)(zero_bytes / 16));
+    hipExtLaunchKernelGGL(fitness_reduce_kernel, dim3(std::min(B, 4 * ctx->num_cus)), dim3(kFitBlock), 0, st, nullptr, evr[2], 0,
+                          offsets, B, shared_scan, (const float *)fit, out, (uint4 *)ws, (unsigned)(zero_bytes / 16));
   }
-  HIP_TRY(ctx, hipEventRecord(evr[2], st));
   ctx->launches++;
   HIP_TRY(ctx, hipGetLastError());
   ctx->ws_clean = zero_bytes;
