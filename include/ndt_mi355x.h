@@ -293,8 +293,9 @@ int ndt_make_map_dev(ndt_ctx *ctx, const float *scans_xy_dev, size_t stride_byte
                      double thre_neighbor, float *out_xy_dev, uint64_t *n_out_dev, void *stream);
 
 /* Durations of the kernels of one of the context's last 64 match launches (`back` = 0: the most recent one):
- * the match kernel (rows a3-a6, a8, a9) and the fitness kernels behind it (row a7), from HIP events recorded around
- * them on the launch's stream.  Blocks until that launch has finished. */
+ * the match kernel (rows a3-a6, a8, a9: start to stop of that kernel) and the fitness kernels behind it (row a7: stop of the
+ * match kernel to stop of the last fitness kernel), from HIP events attached to the kernels' own dispatches on the launch's
+ * stream.  Blocks until that launch has finished. */
 int ndt_kernel_timing(ndt_ctx *ctx, int back, float *match_ms, float *fitness_ms);
 
 /* Timing hooks used by bench.py (HIP events on the context's stream; milliseconds of the most

@@ -89,7 +89,7 @@ struct ndt_ctx {
   // previous one first waits for the previous user (ev_scratch).
   hipEvent_t ev_scratch = nullptr; hipStream_t scratch_stream = nullptr; bool scratch_used = false, scratch_recorded = false;
   size_t ws_clean = 0;                                 // leading bytes of d_ws known to be zero (cleared by the previous launch's last kernel)
-  // ring of timing events around the kernels of the last kTimeRing match launches: start, matches done, fitness done
+  // ring of timing events of the last kTimeRing match launches: match kernel start / stop, fitness_reduce_kernel stop (attached to the dispatches)
   static constexpr int kTimeRing = 64;
   hipEvent_t ev_ring[3 * kTimeRing] = {};
   unsigned long long launches = 0;
