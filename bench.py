@@ -242,13 +242,25 @@ def main():
     torch.cuda.synchronize()
 
     nst = args.steps + args.warmup
-    ev_a = [torch.cuda.Event(enable_timing=True) for _ in range(2 * nst)]
-    ev_m = [torch.cuda.Event(enable_timing=True) for _ in range(2 * nst)]
+    ev_a = [torch.cuda.Event(enable_timing=args.time_builds) for _ in range(2 * nst)]
+    ev_m = [torch.cuda.Event(enable_timing=args.time_builds) for _ in range(2 * nst)]
     best_log = []
     tp_off = capi.RESULT_DTYPE.fields["trans_prob"][1]
     seed_index = (rank + SEED_SHARDS * torch.arange(B, dtype=torch.int64)).to(comm_dev) if c5 else None
 
     open_build = []                                       # the map whose rebuild_end is still owed (one per context)
+    # "step i is done" for other streams: the event the library attaches to the last kernel of the step's launch
+    # (ndt_ctx_wait_launch) -- an event RECORD on the match stream is a packet of its own between two kernels, 6 us per
+    # step (tools/launch_gap.py); records are only made when --time-builds wants their timestamps
+    launch_no, n_launched = {}, [0] * args.inflight
+
+    def wait_step_done(stream, j):
+        if args.time_builds:
+            stream.wait_event(ev_a[2 * j + 1])
+        else:
+            c = j % args.inflight
+            mctx[c].wait_launch(n_launched[c] - 1 - launch_no[j], stream.cuda_stream)
+
 
     def step(i):
         gm = gmaps[i % nbuf]
@@ -256,7 +268,7 @@ def main():
         # a2: rebuild the voxel grid of this step in place, as soon as the matches of step i - nbuf (the last
         # readers of this grid) are done
         if i >= nbuf:
-            bstream.wait_event(ev_a[2 * (i - nbuf) + 1])
+            wait_step_done(bstream, i - nbuf)
         if args.time_builds:
             ev_m[2 * i].record(bstream)
         # two-phase rebuild (ndt_map_rebuild_begin / _end): the build is queued with the voxel grid of the map's last
@@ -267,26 +279,30 @@ def main():
             assert not stale, "the map's bounding box moved: the matches queued on the speculative grid would have to be repeated"
         gm.rebuild_begin(d_map.data_ptr(), len(map_xy), 8)
         open_build.append(gm)
-        ev_m[2 * i + 1].record(bstream)
+        if args.time_builds:
+            ev_m[2 * i + 1].record(bstream)
         # a3-a9 for the whole batch: one launch, after this step's build (the library makes the match stream wait
         # for the build of the map it is given: no second wait here -- every wait is a packet between two kernels)
         out = d_res2[i % nbuf]
         if i >= nbuf and args.inflight > 1:
-            st.wait_event(ev_a[2 * (i - nbuf) + 1])    # the previous writer of this result buffer: another stream when inflight > 1
+            wait_step_done(st, i - nbuf)               # the previous writer of this result buffer: another stream when inflight > 1
         if world > 1:
             st.wait_event(ev_done[i % nbuf])           # the gather that last read this result buffer has finished
         if args.time_builds:
             ev_a[2 * i].record(st)                     # (an event record is a packet between two kernels: timing-only ones are optional)
         gm.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, total_points, d_init.data_ptr(),
                            out.data_ptr(), shared_scan=c5, stream=st.cuda_stream, ctx=cx)
-        ev_a[2 * i + 1].record(st)                     # (also what the rebuild of step i + 2 waits for)
+        launch_no[i] = n_launched[i % args.inflight]
+        n_launched[i % args.inflight] += 1
+        if args.time_builds:
+            ev_a[2 * i + 1].record(st)
         if world > 1 and not c5:    # gather of poses (the only collective on this path)
-            side.wait_stream(st)
+            wait_step_done(side, i)
             with torch.cuda.stream(side):
                 gathered[i % nbuf] = shard.gather_results(out if not rehearsal else out.cpu(), dst=0)
                 ev_done[i % nbuf].record(side)
         if world > 1 and c5:        # configs[4]: arg-max of the hypothesis scores over all ranks (a few bytes)
-            side.wait_stream(st)
+            wait_step_done(side, i)
             with torch.cuda.stream(side):
                 tp = out.view(B, capi.RESULT_BYTES)[:, tp_off:tp_off + 8].contiguous().view(torch.float64).reshape(B)
                 best_log.append(shard.best_hypothesis_t(tp.to(comm_dev), seed_index))    # stays on the device

@@ -297,6 +297,12 @@ int ndt_make_map_dev(ndt_ctx *ctx, const float *scans_xy_dev, size_t stride_byte
  * match kernel to stop of the last fitness kernel), from HIP events attached to the kernels' own dispatches on the launch's
  * stream.  Blocks until that launch has finished. */
 int ndt_kernel_timing(ndt_ctx *ctx, int back, float *match_ms, float *fitness_ms);
+/* Order another stream behind one of the context's last 64 match launches (`back` as above), fitness kernels included:
+ * `stream` (hipStream_t; NULL = the context's stream) waits for the event attached to that launch's last kernel.  What a
+ * caller would otherwise do with hipEventRecord on the launch's stream -- a packet of its own between two kernels
+ * (6 us per launch on the stream that carries the matches) -- e.g. before the map the launch read is rebuilt on
+ * another stream (the reference refills its target cloud every scan, src/ScanMatcher.cpp:40). */
+int ndt_ctx_wait_launch(ndt_ctx *ctx, int back, void *stream);
 
 /* Timing hooks used by bench.py (HIP events on the context's stream; milliseconds of the most
  * recent call of each kind, measured around the kernel launches only). */

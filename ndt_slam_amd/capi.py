@@ -54,7 +54,7 @@ OPT_MAX_HELPERS, OPT_WORKGROUPS = 1, 2                                # ndt_ctx_
 
 EXPORTS = [
     "ndt_default_params", "ndt_params_pcl110", "ndt_params_pcl18", "ndt_params_pcl_new", "ndt_ctx_create", "ndt_ctx_destroy", "ndt_last_error", "ndt_ctx_stream",
-    "ndt_ctx_set_stream", "ndt_ctx_set_option",
+    "ndt_ctx_set_stream", "ndt_ctx_set_option", "ndt_ctx_wait_launch",
     "ndt_map_build", "ndt_map_build_dev", "ndt_map_rebuild_begin", "ndt_map_rebuild_end", "ndt_map_destroy", "ndt_map_info_get", "ndt_map_export",
     "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_trace", "ndt_eval_at",
     "ndt_fitness_at", "ndt_last_timing", "ndt_kernel_timing", "ndt_prefilter", "ndt_prefilter_batch_dev",
@@ -84,6 +84,7 @@ def lib():
     L.ndt_ctx_stream.argtypes = [vp]
     L.ndt_ctx_set_stream.argtypes = [vp, vp]
     L.ndt_ctx_set_option.argtypes = [vp, i, C.c_longlong]
+    L.ndt_ctx_wait_launch.argtypes = [vp, i, vp]
     L.ndt_map_build.argtypes = [vp, vp, sz, sz, C.POINTER(Params), C.POINTER(vp)]
     L.ndt_map_build_dev.argtypes = [vp, vp, sz, sz, C.POINTER(Params), C.POINTER(vp)]
     L.ndt_map_rebuild_begin.argtypes = [vp, vp, sz, sz, C.POINTER(Params), vp]
@@ -175,6 +176,11 @@ class Context:
     def set_option(self, option, value):
         """ndt_ctx_set_option: OPT_MAX_HELPERS (0 = no work sharing), OPT_WORKGROUPS (0 = one per CU)."""
         self.check(lib().ndt_ctx_set_option(self.h, option, value), "ndt_ctx_set_option")
+
+    def wait_launch(self, back, stream=None):
+        """ndt_ctx_wait_launch: `stream` (int handle; None = the context's stream) waits for the match launch `back`
+        launches ago (0 = the most recent), fitness kernels included -- no event record on the launch's stream."""
+        self.check(lib().ndt_ctx_wait_launch(self.h, back, stream), "ndt_ctx_wait_launch")
 
     def prefilter(self, xy, leaf):
         """pcl::ApproximateVoxelGrid on one scan ([n, 2] float32) -> filtered [m, 2] float32."""

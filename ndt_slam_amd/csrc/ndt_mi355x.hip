@@ -421,6 +421,15 @@ int ndt_kernel_timing(ndt_ctx *c, int back, float *match_ms, float *fitness_ms) 
   return NDT_OK;
 }
 
+int ndt_ctx_wait_launch(ndt_ctx *c, int back, void *stream) {
+  if (!c || back < 0 || back >= ndt_ctx::kTimeRing || (unsigned long long)back >= c->launches)
+    return fail(c, NDT_E_ARG, "ndt_ctx_wait_launch: no such launch in the ring");
+  HIP_TRY(c, hipSetDevice(c->device));
+  hipEvent_t *evr = c->ev_ring + 3 * ((c->launches - 1 - (unsigned long long)back) % ndt_ctx::kTimeRing);
+  HIP_TRY(c, hipStreamWaitEvent(stream ? (hipStream_t)stream : c->stream, evr[2], 0));
+  return NDT_OK;
+}
+
 int ndt_map_destroy(ndt_map *m) {
   if (!m) return NDT_E_ARG;
   hipError_t e = hipSetDevice(m->ctx->device);

@@ -500,3 +500,48 @@ def test_map_of_another_device_or_context_is_refused(gpu):
         ctx.check(rc, "ndt_map_build")
     r = gm.align(pts[:50], [0.0, 0.0, 0.0])     # ... but any context of the device may match against it
     assert int(r["status"]) == 0
+
+
+def test_wait_launch_orders_another_stream_behind_a_launch(gpu):
+    """ndt_ctx_wait_launch: a second stream is ordered behind a match launch (fitness kernels included) through the event
+    the library attaches to the launch's last kernel -- no event record on the launch's stream.  The second stream copies
+    the records right behind the wait; only that stream is synchronised."""
+    import torch
+    capi, ctx = gpu
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C3"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    dev = torch.device("cuda", 0)
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    cx = capi.Context(0)
+    with pytest.raises(RuntimeError):
+        cx.wait_launch(0)                                      # nothing launched yet
+    st, other = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    batches = []
+    for first, count in ((0, 64), (100, 200)):
+        scans, off, truths, inits = sf.batch(first, count)
+        batches.append(dict(B=count, n=len(scans), ref=gm.align_batch(scans, off, inits).tobytes(),
+                            scans=torch.from_numpy(scans).to(dev), off=torch.from_numpy(off.astype(np.int64)).to(dev),
+                            init=torch.from_numpy(inits).to(dev),
+                            out=torch.zeros(count * capi.RESULT_BYTES, dtype=torch.uint8, device=dev),
+                            copy=torch.zeros(count * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)))
+    torch.cuda.synchronize()
+    for rep in range(5):
+        for b in batches:
+            b["out"].zero_(); b["copy"].zero_()
+        torch.cuda.synchronize()
+        for b in batches:                                      # two launches back to back on st
+            gm.align_batch_dev(b["scans"].data_ptr(), b["off"].data_ptr(), b["B"], b["n"], b["init"].data_ptr(),
+                               b["out"].data_ptr(), stream=st.cuda_stream, ctx=cx)
+        for back, b in ((1, batches[0]), (0, batches[1])):     # the older launch is one back
+            cx.wait_launch(back, other.cuda_stream)
+            with torch.cuda.stream(other):
+                b["copy"].copy_(b["out"], non_blocking=True)
+        other.synchronize()
+        for k, b in enumerate(batches):
+            assert b["copy"].cpu().numpy().tobytes() == b["ref"], "repetition %d batch %d" % (rep, k)
+    with pytest.raises(RuntimeError):
+        cx.wait_launch(64)                                     # beyond the ring
+    with pytest.raises(RuntimeError):
+        cx.wait_launch(10)                                     # ten launches were made: 0 .. 9 exist
