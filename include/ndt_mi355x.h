@@ -53,8 +53,9 @@ typedef struct ndt_params {
   int    conv_ge;           /* 0: stop when iter > max_iter ; 1: >=              */
   int    radius_inclusive;  /* 0: d^2 < r^2 ; 1: <=                              */
   int    transform_sse;     /* 0: (m00 x + m01 y) + m03 ; 1: m00 x + (m01 y + m03) */
-  int    stale_h_ang;       /* 1: Hessian after an inner line search uses the 2nd-derivative
-                                  angle terms of that line search's first trial  */
+  int    stale_h_ang;       /* 0 (every preset): the Hessian after an inner line search uses the
+                                  2nd-derivative angle terms of the LAST trial (PCL refreshes them on
+                                  every computeDerivatives); 1: those of the line search's first trial */
   double snap_thresh;       /* 10e-5 */
   int    mt_max_iter;       /* 10    */
   double mt_mu;             /* 1e-4  */

@@ -125,15 +125,42 @@ scan_tile_sums_kernel(const int *__restrict__ in, size_t n, int *__restrict__ ti
   if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kScanBlock / 64; ++w) t += sh[w]; tile_sum[blockIdx.x] = t; }
 }
 
+// Grids of more than kScanDirect tiles (8M voxels; ndt_map_build accepts up to 2^28 = 131072 tiles): every workgroup
+// adding up all tile sums in front of it would be O(ntiles^2) loads, so one workgroup turns the tile sums into exclusive
+// offsets first (in place; tile_sum[ntiles] = the grand total) and scan_apply_kernel reads its offset (`prefixed`).
+constexpr int kScanDirect = 4096;
+__global__ void __launch_bounds__(1024)
+scan_tile_offsets_kernel(int *__restrict__ tile_sum, int ntiles) {
+  __shared__ int sh[1024];
+  const int per = (ntiles + 1023) / 1024;
+  const int t0 = min((int)threadIdx.x * per, ntiles), t1 = min(t0 + per, ntiles);
+  int s = 0;
+  for (int t = t0; t < t1; ++t) s += tile_sum[t];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = sh[threadIdx.x] - s;
+  for (int t = t0; t < t1; ++t) { const int v = tile_sum[t]; tile_sum[t] = run; run += v; }
+  if (threadIdx.x == 1023) tile_sum[ntiles] = sh[1023];
+}
+
 __global__ void __launch_bounds__(kScanBlock)
-scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ tile_sum, int ntiles,
+scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ tile_sum, int ntiles, int prefixed,
                   int *__restrict__ out /* n + 1 */,
                   int *__restrict__ big /* voxels with more than kBigVoxel points */, int *__restrict__ nbig, int big_cap) {
   __shared__ int sh[kScanBlock];
   __shared__ int tile_base, grand_total;
   // offset of this tile = sum of the tile sums in front of it (a few hundred values: every workgroup adds them up
   // itself -- a scan kernel of one workgroup between two kernels cost a launch latency for 4 us of work)
-  {
+  if (prefixed) {
+    if (threadIdx.x == 0) { tile_base = tile_sum[blockIdx.x]; grand_total = tile_sum[ntiles]; }
+    __syncthreads();
+  } else {
     int before = 0, all = 0;
     for (int t = threadIdx.x; t < ntiles; t += kScanBlock) { const int v = tile_sum[t]; all += v; if (t < (int)blockIdx.x) before += v; }
 #pragma unroll
@@ -262,14 +289,14 @@ __device__ int leaf_finalize(const LeafParams &L, int n, double sx, double sy, d
   double cxx, cxy, cyy, czz;
   if (!L.cov_unbiased) {
     cxx = (sxx - 2.0 * (sx * mx)) / dn + mx * mx;
-    cxy = (sxy - 2.0 * (sx * my)) / dn + mx * my;
+    cxy = (sxy - 2.0 * (sy * mx)) / dn + my * mx;     // the LOWER-triangle entry (1,0): what Eigen's solver reads
     cyy = (syy - 2.0 * (sy * my)) / dn + my * my;
     czz = szz / dn;
     const double f = (dn - 1.0) / dn;
     cxx *= f; cxy *= f; cyy *= f; czz *= f;
   } else {
     cxx = (sxx - sx * mx) / (dn - 1.0);
-    cxy = (sxy - sx * my) / (dn - 1.0);
+    cxy = (sxy - sy * mx) / (dn - 1.0);
     cyy = (syy - sy * my) / (dn - 1.0);
     czz = szz / (dn - 1.0);
   }

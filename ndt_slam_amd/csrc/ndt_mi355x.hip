@@ -272,7 +272,7 @@ static void params_common(ndt_params *p) {
   memset(p, 0, sizeof(*p));
   p->resolution = 1.0f; p->step_size = 0.1; p->trans_eps = 0.01; p->max_iter = 35;   // PoseEstimator.h:63-64
   p->outlier_ratio = 0.55; p->min_pts = 6; p->eig_mult = 0.01;
-  p->conv_ge = 0; p->radius_inclusive = 0; p->stale_h_ang = 1;
+  p->conv_ge = 0; p->radius_inclusive = 0; p->stale_h_ang = 0;
   p->snap_thresh = 10e-5; p->mt_max_iter = 10; p->mt_mu = 1.e-4; p->mt_nu = 0.9;
 }
 
@@ -390,7 +390,9 @@ int ndt_ctx_set_stream(ndt_ctx *c, void *stream) {
   if (!c) return NDT_E_ARG;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  c->scratch_used = false;                             // (everything queued so far has finished)
+  // the last user of the scratch may have been a *_dev call on a foreign stream (its event was recorded then)
+  if (c->scratch_used && c->scratch_recorded) HIP_TRY(c, hipEventSynchronize(c->ev_scratch));
+  c->scratch_used = false; c->scratch_recorded = false;   // (everything queued so far has finished)
   c->stream = stream ? (hipStream_t)stream : c->own_stream;
   return NDT_OK;
 }
@@ -433,7 +435,12 @@ int ndt_ctx_wait_launch(ndt_ctx *c, int back, void *stream) {
 int ndt_map_destroy(ndt_map *m) {
   if (!m) return NDT_E_ARG;
   hipError_t e = hipSetDevice(m->ctx->device);
+  if (m->ctx->pending_map == m) {               // an open ndt_map_rebuild_begin dies with its map
+    if (m->ctx->side) e = hipStreamSynchronize(m->ctx->side);
+    m->ctx->pending_map = nullptr;
+  }
   e = hipStreamSynchronize(m->ctx->stream);
+  if (m->ctx->side) e = hipStreamSynchronize(m->ctx->side);
   void *bufs[] = {m->occ, m->big, m->count, m->start, m->tile, m->npts_grid, m->perm, m->perm_sorted, m->pts,
                   m->cent, m->rec, m->bounds, m->counters, m->total, m->d_xy_stage};
   for (void *b : bufs) if (b) e = hipFree(b);
@@ -445,7 +452,7 @@ int ndt_map_destroy(ndt_map *m) {
 // Steps 2-4 of the map build for a given voxel grid: everything after the bounding box, queued on
 // the context's stream.
 static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size_t stride, const ndt_params *prm,
-                       const GridDims &G) {
+                       const GridDims &G, bool requeue = false) {
   hipStream_t st = ctx->stream;
   const float inv_leaf = G.inv_leaf;
   const size_t ng = (size_t)G.div_x * G.div_y, npad = (size_t)G.gw * G.gh;
@@ -476,6 +483,14 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   m->count_clean = false;
   // (records of voxels outside the search set are never read: no clearing of m->rec)
   // (the centroid grid is reset on the side stream, beside the bucketing chain; joined in front of the statistics)
+  // A build queued AGAIN (build_end found the speculative grid wrong) must not reset the grid before the speculative
+  // build's statistics kernel -- on the main stream, writing centroids at the stale grid's indices -- has finished:
+  // the side stream was forked only once, in build_begin.  Its centroids would otherwise survive the reset as phantom
+  // voxels (the slow path of ndt_point.hip.h reads the grid without an occupancy test).
+  if (requeue) {
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  }
   fill_f2_kernel<<<grid_for(npad, 256), 256, 0, ctx->side>>>(m->cent, npad, INFINITY);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
 
@@ -485,7 +500,9 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   scan_tile_sums_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, m->counters);
   int *const start = m->start + 4;
   const int big_cap = (int)(n / kBigVoxel + 1);
-  scan_apply_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, ntiles, start, m->big, m->counters + 2, big_cap);
+  const int prefixed = ntiles > kScanDirect ? 1 : 0;
+  if (prefixed) scan_tile_offsets_kernel<<<1, 1024, 0, st>>>(m->tile, ntiles);
+  scan_apply_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, ntiles, prefixed, start, m->big, m->counters + 2, big_cap);
   map_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, start, m->count, m->perm);
   HIP_TRY(ctx, hipGetLastError());
   m->count_clean = true;
@@ -565,7 +582,7 @@ static int build_end(ndt_ctx *ctx, ndt_map *m) {
                     G.div_x == m->grid.div_x && G.div_y == m->grid.div_y;
   int redone = 0;
   if (!same) {
-    int rc = queue_build(ctx, m, m->pend_xy, m->n, m->pend_stride, prm, G);
+    int rc = queue_build(ctx, m, m->pend_xy, m->n, m->pend_stride, prm, G, /*requeue=*/m->pend_queued);
     if (rc) return rc;
     redone = m->pend_queued ? 1 : 0;
   }

@@ -228,7 +228,7 @@ def yaw_from_T(T00, T10):
 
 
 def align(cells, scan32, init, resolution, step_size=0.1, trans_eps=0.01, max_iter=35,
-          outlier_ratio=0.55, stale_h_ang=True, mu=1e-4, nu=0.9, mt_max=10, sse=True):
+          outlier_ratio=0.55, stale_h_ang=False, mu=1e-4, nu=0.9, mt_max=10, sse=True):
     """Newton + More-Thuente driver (Magnusson Algorithm 2 with PCL's step clamp)."""
     d1, d2 = gauss_constants(resolution, outlier_ratio)
     scan32 = np.ascontiguousarray(scan32, dtype=F)

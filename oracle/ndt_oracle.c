@@ -38,7 +38,7 @@ static void params_common(ndt_oracle_params *p) {
   p->eig_mult = 0.01;
   p->conv_ge = 0;
   p->radius_inclusive = 0;
-  p->stale_h_ang = 1;
+  p->stale_h_ang = 0;    /* computeDerivatives calls computeAngleDerivatives(p) with its default compute_hessian = true */
   p->snap_thresh = 10e-5;
   p->mt_max_iter = 10;
   p->mt_mu = 1.e-4;
@@ -123,14 +123,16 @@ static int leaf_finalize(const ndt_oracle_params *prm, int n, double sx, double 
   if (!prm->cov_unbiased) {
     /* cov = (Sxx - 2 (sum mu^T)) / n + mu mu^T ; cov *= (n-1)/n */
     cxx = (sxx - 2.0 * (sx * mx)) / dn + mx * mx;
-    cxy = (sxy - 2.0 * (sx * my)) / dn + mx * my;
+    /* pt_sum * mean^T is not symmetric in floating point; SelfAdjointEigenSolver reads the LOWER triangle,
+     * entry (1,0) = (Syx - 2 (sum_y mu_x)) / n + mu_y mu_x */
+    cxy = (sxy - 2.0 * (sy * mx)) / dn + my * mx;
     cyy = (syy - 2.0 * (sy * my)) / dn + my * my;
     czz = szz / dn;
     double f = (dn - 1.0) / dn;
     cxx *= f; cxy *= f; cyy *= f; czz *= f;
   } else {
     cxx = (sxx - sx * mx) / (dn - 1.0);
-    cxy = (sxy - sx * my) / (dn - 1.0);
+    cxy = (sxy - sy * mx) / (dn - 1.0);     /* lower-triangle entry, as above */
     cyy = (syy - sy * my) / (dn - 1.0);
     czz = szz / (dn - 1.0);
   }

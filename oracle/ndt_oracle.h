@@ -47,9 +47,11 @@ typedef struct ndt_oracle_params {
   int    conv_ge;           /* (2) 0: stop when iter > max_iter  1: iter >= max_iter           */
   int    radius_inclusive;  /* (4) 0: d^2 < r^2                  1: d^2 <= r^2                 */
   int    transform_sse;     /* (12) 0: ((m00 x + m01 y) + m03)   1: m00 x + (m01 y + m03)      */
-  int    stale_h_ang;       /* (8) 1: Hessian-only pass after an MT inner loop re-uses the
-                                     2nd-derivative angle terms of the FIRST trial of that
-                                     line search (PCL computeHessian does not refresh them)   */
+  int    stale_h_ang;       /* (8) 0 (every preset): computeDerivatives refreshes j_ang AND h_ang on every
+                                     trial (it calls computeAngleDerivatives(p) with the default
+                                     compute_hessian = true), so computeHessian after an inner loop sees
+                                     the terms of the LAST trial.  1: a PCL whose inner trials would skip
+                                     the h_ang refresh (terms of the line search's FIRST trial)       */
   double snap_thresh;       /* (6) small-angle snap, PCL `fabs(p) < 10e-5`                     */
   int    mt_max_iter;       /* (11) 10                                                         */
   double mt_mu;             /* (11) 1e-4                                                       */

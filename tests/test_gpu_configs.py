@@ -35,13 +35,34 @@ def world_5m():
     return m, synth.ScanFactory(m, cfg["half"], cfg["n_scan"]), cfg
 
 
-def test_c4_2048_scans_one_launch_vs_oracle_and_shards(gpu, oracle, world_1m):
+# Both settings of `stale_h_ang` at full size (the default, 0, is what PCL's computeDerivatives does --
+# the angle terms of the Hessian are refreshed on every trial; 1 is kept as a switch).
+STALE = [0, 1]
+
+
+@pytest.mark.parametrize("stale", STALE)
+def test_c3_full_batch_every_scan_vs_oracle(gpu, oracle, world_1m, stale):
+    """configs[2]: all 256 scans of the bench batch against the oracle, under both settings of stale_h_ang."""
+    capi, ctx = gpu
+    m, sf, cfg = world_1m
+    scans, off, truths, inits = sf.batch(0, 256)
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"], stale_h_ang=stale))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"], stale_h_ang=stale))
+    res = gm.align_batch(scans, off, inits)
+    ref = om.align_batch(scans, off, inits, nthreads=NTHREADS)
+    for b in range(256):
+        assert_result_parity(res[b], ref[b])
+    assert np.array_equal(res["iters"], ref["iters"]) and np.array_equal(res["ref_evals"], ref["ref_evals"])
+
+
+@pytest.mark.parametrize("stale", STALE)
+def test_c4_2048_scans_one_launch_vs_oracle_and_shards(gpu, oracle, world_1m, stale):
     capi, ctx = gpu
     m, sf, cfg = world_1m
     B = cfg["batch"]
     assert B == 2048
     scans, off, truths, inits = sf.batch(0, B)
-    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"], stale_h_ang=stale))
     res = gm.align_batch(scans, off, inits)                       # one launch, 2048 scans on 256 workgroups
     assert np.all(res["status"] == 0) and np.all(res["converged"] == 1)
     # configs[3] shards: eight launches of 256 scans give the same records, byte for byte
@@ -50,7 +71,7 @@ def test_c4_2048_scans_one_launch_vs_oracle_and_shards(gpu, oracle, world_1m):
         part = gm.align_batch(scans[int(off[lo]):int(off[hi])], off[lo:hi + 1] - off[lo], inits[lo:hi])
         assert part.tobytes() == res[lo:hi].tobytes(), "shard %d differs from the 2048-scan launch" % r
     # the oracle on every scan
-    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"], stale_h_ang=stale))
     ref = om.align_batch(scans, off, inits, nthreads=NTHREADS)
     for b in range(B):
         assert_result_parity(res[b], ref[b])
@@ -59,16 +80,17 @@ def test_c4_2048_scans_one_launch_vs_oracle_and_shards(gpu, oracle, world_1m):
     assert np.array_equal(res["iters"], ref["iters"])
 
 
-def test_c5_4096_seeds_shared_scan_vs_oracle_and_shards(gpu, oracle, world_5m):
+@pytest.mark.parametrize("stale", STALE)
+def test_c5_4096_seeds_shared_scan_vs_oracle_and_shards(gpu, oracle, world_5m, stale):
     capi, ctx = gpu
     from ndt_slam_amd import synth
     m, sf, cfg = world_5m
     scan, truth, _ = sf.make(0)
     seeds = synth.hypothesis_seeds(truth, cfg["seeds"])
     assert len(seeds) == 4096
-    prm = capi.default_params(resolution=cfg["resolution"])
+    prm = capi.default_params(resolution=cfg["resolution"], stale_h_ang=stale)
     gm = capi.Map(ctx, m, prm)
-    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"]))
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"], stale_h_ang=stale))
     # the 5M-point voxel grid itself
     gi, oi = gm.info(), om.info()
     assert (gi.min_bx, gi.min_by, gi.div_x, gi.div_y, gi.n_cells, gi.n_valid) == \

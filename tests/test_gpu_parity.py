@@ -123,6 +123,75 @@ def test_two_phase_rebuild(gpu, oracle, c1_world):
         other.rebuild_begin(d_m.data_ptr(), len(m), 8)     # no earlier build at this resolution
 
 
+def test_rebuild_with_a_moved_bounding_box_leaves_no_phantom_voxels(gpu, oracle, c1_world):
+    """A rebuild whose bounding box moved by ONE voxel (same grid size, so the centroid buffer is re-used): the build
+    queued ahead with the previous grid writes centroids and records at stale indices; the build queued again must
+    reset the grid AFTER that kernel has finished (round-2 advisor finding: the reset ran on the side stream, ordered
+    only behind the first reset).  `ndt_eval_at` reads the dense grid without the occupancy bitmap -- a phantom
+    centroid shows up as a voxel found twice: the pair count and every sum differ from a fresh build."""
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    res = cfg["resolution"]
+    prm = capi.default_params(resolution=res)
+    for shift in ((res, 0.0), (0.0, -res), (res, res)):
+        moved = (m + np.array(shift, np.float32)).astype(np.float32)
+        gm = capi.Map(ctx, m, prm)
+        gi0 = gm.info()
+        gm.rebuild(xy=moved)                                  # begin + end back to back: the common SLAM call
+        fresh = capi.Map(ctx, moved, prm)
+        gi, fi = gm.info(), fresh.info()
+        assert (gi.min_bx, gi.min_by, gi.div_x, gi.div_y, gi.n_cells, gi.n_valid) == \
+               (fi.min_bx, fi.min_by, fi.div_x, fi.div_y, fi.n_cells, fi.n_valid)
+        assert (gi.min_bx, gi.min_by) != (gi0.min_bx, gi0.min_by)
+        om = oracle.Map(moved, oracle.default_params(resolution=res))
+        for k in range(3):
+            scan, truth, init = sf.make(k)
+            for p in (truth, init):
+                q = [p[0] + shift[0], p[1] + shift[1], p[2]]
+                s, g, H, pairs = gm.eval_at(scan, q)
+                s1, g1, H1, pairs1 = fresh.eval_at(scan, q)
+                assert pairs == pairs1 == om.eval_at(scan, q)[3]
+                assert (s, g.tobytes(), H.tobytes()) == (s1, g1.tobytes(), H1.tobytes())
+        gm.close(); fresh.close()
+
+
+def test_map_destroy_closes_an_open_rebuild(gpu, c1_world):
+    """ndt_map_destroy on a map with an open ndt_map_rebuild_begin: the context must be usable afterwards."""
+    import torch
+    capi, ctx2 = gpu[0], gpu[0].Context(0)
+    m, sf, cfg = c1_world
+    prm = capi.default_params(resolution=cfg["resolution"])
+    gm = capi.Map(ctx2, m, prm)
+    d_m = torch.from_numpy(m).cuda()
+    torch.cuda.synchronize()
+    gm.rebuild_begin(d_m.data_ptr(), len(m), 8)
+    gm.close()
+    again = capi.Map(ctx2, m, prm)                            # would fail with "rebuild_end is still owed"
+    scan, truth, init = sf.make(0)
+    assert int(again.align(scan, init)["status"]) == 0
+
+
+def test_sparse_grid_above_the_direct_scan_limit(gpu, oracle):
+    """A grid of more than 4096 scan tiles (8.4M voxels): the bucket offsets come from the one-workgroup tile scan
+    (scan_tile_offsets_kernel) instead of every workgroup adding up all tile sums in front of it."""
+    capi, ctx = gpu
+    rng = np.random.default_rng(11)
+    a = rng.normal(0.0, 3.0, size=(6000, 2))
+    b = rng.normal(0.0, 3.0, size=(6000, 2)) + np.array([1790.0, 1530.0])
+    pts = np.concatenate([a, b]).astype(np.float32)[rng.permutation(12000)]
+    prm = dict(resolution=0.5)
+    gm = capi.Map(ctx, pts, capi.default_params(**prm))
+    om = oracle.Map(pts, oracle.default_params(**prm))
+    gi, oi = gm.info(), om.info()
+    assert gi.div_x * gi.div_y > 4096 * 2048
+    assert (gi.min_bx, gi.min_by, gi.div_x, gi.div_y, gi.n_cells, gi.n_valid) == \
+           (oi.min_bx, oi.min_by, oi.div_x, oi.div_y, oi.n_cells, oi.n_valid)
+    g, o = gm.export(), om.export()
+    for k in ("idx", "npts", "cent", "mean"):
+        assert np.array_equal(g[k], o[k]), k
+    gm.close()
+
+
 # ------------------------------------------------------------------------------------------ a4 + a5
 def test_single_evaluation_matches_oracle(gpu, oracle, c1_world):
     capi, ctx = gpu
@@ -223,7 +292,7 @@ def test_yaw_strata_near_90_and_180(gpu, oracle, c1_world):
         assert_result_parity(r, ref)
 
 
-@pytest.mark.parametrize("kw", [dict(transform_sse=0), dict(stale_h_ang=0), dict(conv_ge=1, max_iter=3),
+@pytest.mark.parametrize("kw", [dict(transform_sse=0), dict(stale_h_ang=1), dict(conv_ge=1, max_iter=3),
                                 dict(radius_inclusive=1), dict(cov_init_identity=0), dict(step_size=0.05, trans_eps=0.02),
                                 dict(preset="pcl18"), dict(preset="pcl_new")])
 def test_version_switches_follow_the_oracle(gpu, oracle, c1_world, kw):

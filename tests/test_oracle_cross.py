@@ -170,7 +170,7 @@ def test_version_switches_are_live(oracle, c1_world):
     m, sf, cfg = c1_world
     scan, truth, init = sf.make(0)
     base = oracle.Map(m, oracle.default_params(resolution=0.3)).align(scan, init)
-    for kw in (dict(transform_sse=0), dict(stale_h_ang=0), dict(cov_unbiased=1), dict(cov_init_identity=0)):
+    for kw in (dict(transform_sse=0), dict(stale_h_ang=1), dict(cov_unbiased=1), dict(cov_init_identity=0)):
         r = oracle.Map(m, oracle.default_params(resolution=0.3, **kw)).align(scan, init)
         assert r["status"] == 0
-        assert abs(r["score"] - base["score"]) > 0 or kw == dict(stale_h_ang=0)
+        assert abs(r["score"] - base["score"]) > 0 or kw == dict(stale_h_ang=1)
