@@ -525,29 +525,65 @@ __device__ __noinline__ bool sort_points(const MapView &M, const Tf32 &T0, const
   return true;
 }
 
-// Sum of 12 per-lane values over the 64 lanes of a wave in a fixed order, 86 instructions instead
-// of 12 x 18: a butterfly in which every exchange also halves the number of values a lane carries
-// (12 -> 6 -> 3 -> 2 -> 1), so only 24 cross-lane moves are needed.  The total of value j ends in
-// the lanes whose bits select j; those lanes store it to dst[j] (LDS).
+// Sum of 12 per-lane values over the 64 lanes of a wave in a fixed order: a butterfly in which every exchange also
+// halves the number of values a lane carries (12 -> 6 -> 3 -> 2 -> 1).  The total of value j ends in the lanes whose
+// bits select j; those lanes store it to dst[j] (LDS).
+//
+// Round 3: the exchanges are gfx950 cross-lane VALU moves instead of 24 x 2 ds_bpermute_b32 through the LDS pipe (each
+// stage waited ~100 cycles for its shuffles: ~1 us per unit on a wave that has nothing else to issue -- the helpers'
+// lone waves).  v_permlane32_swap / v_permlane16_swap (new in CDNA4) exchange the halves / odd-even rows of TWO
+// registers in one instruction, which is exactly the "keep one half, send the other" step, so the selects vanish too;
+// the xor-8 / xor-4 / xor-2 / xor-1 exchanges are DPP row rotations and quad permutes with bank masks.  Same pairs of
+// lanes, same additions: the sums are bit-identical to the shuffle version (fp addition commutes).
+__device__ __forceinline__ unsigned dlo(double x) { return (unsigned)__double_as_longlong(x); }
+__device__ __forceinline__ unsigned dhi(double x) { return (unsigned)((u64)__double_as_longlong(x) >> 32); }
+__device__ __forceinline__ double dmk(unsigned lo, unsigned hi) { return __longlong_as_double((long long)(((u64)hi << 32) | lo)); }
+// lanes 0..31: x(l) + x(l + 32);  lanes 32..63: y(l - 32) + y(l)
+__device__ __forceinline__ double swap32_add(double x, double y) {
+  const auto a = __builtin_amdgcn_permlane32_swap(dlo(x), dlo(y), false, false);
+  const auto b = __builtin_amdgcn_permlane32_swap(dhi(x), dhi(y), false, false);
+  return dmk(a[0], b[0]) + dmk(a[1], b[1]);
+}
+// rows of 16 lanes; even rows: x(l) + x(l + 16);  odd rows: y(l - 16) + y(l)
+__device__ __forceinline__ double swap16_add(double x, double y) {
+  const auto a = __builtin_amdgcn_permlane16_swap(dlo(x), dlo(y), false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(dhi(x), dhi(y), false, false);
+  return dmk(a[0], b[0]) + dmk(a[1], b[1]);
+}
+// DPP move of a double: lanes enabled by BANKS (one bit per group of four lanes of a row) take src from the lane CTRL
+// names, the others keep `old`
+template <int CTRL, int BANKS>
+__device__ __forceinline__ double dpp_d(double old, double src) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)dlo(old), (int)dlo(src), CTRL, 0xF, BANKS, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)dhi(old), (int)dhi(src), CTRL, 0xF, BANKS, false);
+  return dmk(lo, hi);
+}
+constexpr int kDppRor4 = 0x124, kDppRor8 = 0x128, kDppRor12 = 0x12C;    // row_ror:n -- lane l reads lane (l - n) mod 16 of its row
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E;                         // quad_perm [1,0,3,2] / [2,3,0,1]
+// lanes whose bit `8` (BIT8) or bit `4` is clear: x(l) + x(l + d);  set: y(l - d) + y(l)      (d = 8 or 4)
+__device__ __forceinline__ double xor8_add(double x, double y) {
+  const double keep = dpp_d<kDppRor8, 0xC>(x, y);     // lanes 8..15 of a row: y(l - 8)
+  const double recv = dpp_d<kDppRor8, 0x3>(y, x);     // lanes 0..7:          x(l + 8)
+  return keep + recv;
+}
+__device__ __forceinline__ double xor4_add(double x, double y) {
+  const double keep = dpp_d<kDppRor4, 0xA>(x, y);     // lanes 4..7, 12..15: y(l - 4)
+  const double recv = dpp_d<kDppRor12, 0x5>(y, x);    // lanes 0..3, 8..11:  x(l + 4)
+  return keep + recv;
+}
 __device__ __forceinline__ void wave_reduce12(const double (&a)[12], int lane, double *__restrict__ dst) {
   const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
   double k[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) {                       // keep values 0..5 (b5 = 0) or 6..11 (b5 = 1)
-    const double keep = b5 ? a[i + 6] : a[i], send = b5 ? a[i] : a[i + 6];
-    k[i] = keep + __shfl_xor(send, 32);
-  }
+  for (int i = 0; i < 6; ++i) k[i] = swap32_add(a[i], a[i + 6]);          // values 0..5 (b5 = 0) or 6..11 (b5 = 1)
   double m[3];
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {                       // keep 0..2 or 3..5 of those
-    const double keep = b4 ? k[i + 3] : k[i], send = b4 ? k[i] : k[i + 3];
-    m[i] = keep + __shfl_xor(send, 16);
-  }
-  const double p0 = (b3 ? m[1] : m[0]) + __shfl_xor(b3 ? m[0] : m[1], 8);   // value 0 or 1 of the triple
-  const double p1 = m[2] + __shfl_xor(m[2], 8);                            // value 2
-  double r = (b2 ? p1 : p0) + __shfl_xor(b2 ? p0 : p1, 4);
-  r += __shfl_xor(r, 2);
-  r += __shfl_xor(r, 1);
+  for (int i = 0; i < 3; ++i) m[i] = swap16_add(k[i], k[i + 3]);          // 0..2 or 3..5 of those
+  const double p0 = xor8_add(m[0], m[1]);                                 // value 0 or 1 of the triple
+  const double p1 = m[2] + dpp_d<kDppRor8, 0xF>(m[2], m[2]);              // value 2
+  double r = xor4_add(p0, p1);
+  r += dpp_d<kDppXor2, 0xF>(r, r);
+  r += dpp_d<kDppXor1, 0xF>(r, r);
   const int idx = (b5 ? 6 : 0) + (b4 ? 3 : 0) + (b2 ? 2 : (b3 ? 1 : 0));
   if ((lane & 3) == 0 && !(b2 && b3)) dst[idx] = r;
 }
