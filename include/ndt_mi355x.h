@@ -298,6 +298,12 @@ int ndt_make_map_dev(ndt_ctx *ctx, const float *scans_xy_dev, size_t stride_byte
  * match kernel to stop of the last fitness kernel), from HIP events attached to the kernels' own dispatches on the launch's
  * stream.  Blocks until that launch has finished. */
 int ndt_kernel_timing(ndt_ctx *ctx, int back, float *match_ms, float *fitness_ms);
+/* Time from the start of the match kernel of launch `back + 1` to the start of the match kernel of launch `back` of
+ * this context, from the same events: the step-to-step interval of a caller that issues launches back to back
+ * (bench.py: ms_per_step_min / _max over the timed steps, without a further event record on the match stream).
+ * Both launches must still be among the last 64.  Replaces the reference's per-scan "align time" log
+ * (src/PoseEstimator.cpp:15,38-40). */
+int ndt_launch_interval(ndt_ctx *ctx, int back, float *interval_ms);
 /* Order another stream behind one of the context's last 64 match launches (`back` as above), fitness kernels included:
  * `stream` (hipStream_t; NULL = the context's stream) waits for the event attached to that launch's last kernel.  What a
  * caller would otherwise do with hipEventRecord on the launch's stream -- a packet of its own between two kernels

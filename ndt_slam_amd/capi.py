@@ -57,7 +57,7 @@ EXPORTS = [
     "ndt_ctx_set_stream", "ndt_ctx_set_option", "ndt_ctx_wait_launch",
     "ndt_map_build", "ndt_map_build_dev", "ndt_map_rebuild_begin", "ndt_map_rebuild_end", "ndt_map_destroy", "ndt_map_info_get", "ndt_map_export",
     "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_trace", "ndt_eval_at",
-    "ndt_fitness_at", "ndt_last_timing", "ndt_kernel_timing", "ndt_prefilter", "ndt_prefilter_batch_dev",
+    "ndt_fitness_at", "ndt_last_timing", "ndt_kernel_timing", "ndt_launch_interval", "ndt_prefilter", "ndt_prefilter_batch_dev",
     "ndt_fuse_default_params", "ndt_predict_batch_dev", "ndt_fuse_batch_dev",
     "ndt_remove_neighbors", "ndt_remove_neighbors_dev",
     "ndt_difference_extraction", "ndt_difference_extraction_dev", "ndt_make_map", "ndt_make_map_dev",
@@ -100,6 +100,7 @@ def lib():
     L.ndt_fitness_at.argtypes = [vp, vp, vp, sz, sz, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     L.ndt_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ndt_kernel_timing.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ndt_launch_interval.argtypes = [vp, i, C.POINTER(C.c_float)]
     L.ndt_prefilter.argtypes = [vp, vp, sz, sz, C.c_float, vp, C.POINTER(sz)]
     L.ndt_prefilter_batch_dev.argtypes = [vp, vp, sz, vp, i, sz, C.c_float, vp, vp, vp]
     L.ndt_fuse_default_params.argtypes = [C.POINTER(FuseParams)]
@@ -263,6 +264,12 @@ class Context:
         a, b = C.c_float(), C.c_float()
         self.check(lib().ndt_kernel_timing(self.h, back, C.byref(a), C.byref(b)), "ndt_kernel_timing")
         return a.value, b.value
+
+    def launch_interval(self, back=0):
+        """ms from the start of the match kernel of launch back + 1 to the start of launch back (both among the last 64)."""
+        a = C.c_float()
+        self.check(lib().ndt_launch_interval(self.h, back, C.byref(a)), "ndt_launch_interval")
+        return a.value
 
     def close(self):
         if self.h:

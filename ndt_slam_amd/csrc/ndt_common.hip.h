@@ -21,6 +21,7 @@ struct MapView {
   const int *pt_start;               // div_x*div_y + 1 bucket offsets of the raw points
   const float2 *pts;                 // raw points bucketed by voxel, input order kept (a7)
   double d1, d2;                     // Gaussian constants (a3)
+  double e_hi;                       // pairs with exp(..) > e_hi fail updateDerivatives' `d2 e in [0, 1]` check (ndt_point.hip.h)
 };
 
 struct OptParams {
@@ -50,6 +51,7 @@ struct AlignState {
   double phi0, dphi0, a_l, f_l, g_l, a_u, f_u, g_u, a_t;
   double pairs;
   double n_points;
+  int need_tf;                  // set_trial: bit 0 = the trial's transforms are still to be formed (trial_transforms), bit 1 = with the Hessian angle terms
 };
 
 // ------------------------------------------------------------------------------------------

@@ -346,6 +346,9 @@ __device__ __forceinline__ int write_voxel(const GridDims &G, const LeafParams &
   cent[pg] = make_float2(fx / (float)n, fy / (float)n);
   double *r = rec + pg * 8;
   r[0] = mean[0]; r[1] = mean[1]; r[2] = icov[0]; r[3] = icov[1]; r[4] = icov[2];
+  // the float32 centroid once more, in the record's own 64-byte line: the window staging of the match kernel then reads
+  // ONE line per voxel instead of the record line + a line of the centroid grid (fill_window)
+  r[5] = __longlong_as_double((long long)(((u64)__float_as_uint(fy / (float)n) << 32) | (u64)__float_as_uint(fx / (float)n)));
   return ok > 0 ? n : -n;
 }
 

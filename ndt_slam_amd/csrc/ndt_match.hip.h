@@ -187,30 +187,9 @@ __device__ __forceinline__ Window window_of(const Region &R, const uint4 *pool) 
   return W;
 }
 
-// Owner: bounding box of the scan's voxel coordinates at the first pose -> window geometry.
-template <bool SSE>
-__device__ __noinline__ void compute_region(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
-                                               int n, Lds &L) {
-  if (threadIdx.x == 0) { L.sbox[0] = INT_MAX; L.sbox[1] = INT_MAX; L.sbox[2] = INT_MIN; L.sbox[3] = INT_MIN; }
-  __syncthreads();
-  int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
-  for (int i = threadIdx.x; i < n; i += kBlock) {
-    const float2 pt = scan[i];
-    float xt, yt;
-    tf_apply_t<SSE>(T0, pt.x, pt.y, xt, yt);
-    if (!finite2(xt, yt)) continue;
-    const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
-    const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
-    const int ix = (int)fx - M.min_bx, iy = (int)fy - M.min_by;
-    mnx = ix < mnx ? ix : mnx; mxx = ix > mxx ? ix : mxx;
-    mny = iy < mny ? iy : mny; mxy = iy > mxy ? iy : mxy;
-  }
-  mnx = wave_min_i(mnx); mny = wave_min_i(mny); mxx = wave_max_i(mxx); mxy = wave_max_i(mxy);
-  if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
-    atomicMin(&L.sbox[0], mnx); atomicMin(&L.sbox[1], mny); atomicMax(&L.sbox[2], mxx); atomicMax(&L.sbox[3], mxy);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
+// thread 0: window geometry from the bounding box of the scan's voxel coordinates (L.sbox) -> L.RG, L.clipped
+__device__ __forceinline__ void region_from_bbox(const MapView &M, Lds &L) {
+  {
     Region r = {0, 0, 0, 0, 0, 0};
     L.clipped = 0;
     if (L.sbox[0] <= L.sbox[2]) {
@@ -236,6 +215,32 @@ __device__ __noinline__ void compute_region(const MapView &M, const Tf32 &T0, co
     r.cap = cap > 0xFFF0 ? 0xFFF0 : cap;
     L.RG = r;
   }
+}
+
+// Owner: bounding box of the scan's voxel coordinates at the first pose -> window geometry.
+template <bool SSE>
+__device__ __noinline__ void compute_region(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
+                                               int n, Lds &L) {
+  if (threadIdx.x == 0) { L.sbox[0] = INT_MAX; L.sbox[1] = INT_MAX; L.sbox[2] = INT_MIN; L.sbox[3] = INT_MIN; }
+  __syncthreads();
+  int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    const float2 pt = scan[i];
+    float xt, yt;
+    tf_apply_t<SSE>(T0, pt.x, pt.y, xt, yt);
+    if (!finite2(xt, yt)) continue;
+    const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const int ix = (int)fx - M.min_bx, iy = (int)fy - M.min_by;
+    mnx = ix < mnx ? ix : mnx; mxx = ix > mxx ? ix : mxx;
+    mny = iy < mny ? iy : mny; mxy = iy > mxy ? iy : mxy;
+  }
+  mnx = wave_min_i(mnx); mny = wave_min_i(mny); mxx = wave_max_i(mxx); mxy = wave_max_i(mxy);
+  if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
+    atomicMin(&L.sbox[0], mnx); atomicMin(&L.sbox[1], mny); atomicMax(&L.sbox[2], mxx); atomicMax(&L.sbox[3], mxy);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) region_from_bbox(M, L);
   __syncthreads();
 }
 
@@ -372,7 +377,7 @@ __device__ __noinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool, 
     constexpr int kRecPer = 4;
     const int kept = min(L.swave[0] + L.swave[1] + L.swave[2] + L.swave[3], r.cap);
     static_assert(kPoolBytes / (int)sizeof(CellEntry) <= kRecPer * kBlock, "a thread fetches at most kRecPer records");
-    int nx[kRecPer]; float2 cc[kRecPer]; double2 ra[kRecPer], rb[kRecPer]; double rc[kRecPer];
+    int nx[kRecPer]; double2 ra[kRecPer], rb[kRecPer], rc[kRecPer];     // rc.y: the float32 centroid (map_build: write_voxel)
 #pragma unroll
     for (int u = 0; u < kRecPer; ++u) {
       const int k = (int)threadIdx.x + u * kBlock;
@@ -396,15 +401,17 @@ __device__ __noinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool, 
         const int ly = c / r.rw, lx = c - ly * r.rw;
         const size_t pg = (size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2);
         const double *rec = M.rec + pg * 8;
-        cc[u] = M.cent[pg];
-        ra[u] = *reinterpret_cast<const double2 *>(rec); rb[u] = *reinterpret_cast<const double2 *>(rec + 2); rc[u] = rec[4];
+        ra[u] = *reinterpret_cast<const double2 *>(rec); rb[u] = *reinterpret_cast<const double2 *>(rec + 2);
+        rc[u] = *reinterpret_cast<const double2 *>(rec + 4);
         nx[u] = k;
       }
     }
 #pragma unroll
     for (int u = 0; u < kRecPer; ++u) {
       if (nx[u] >= 0) {
-        CellEntry E; E.cent = cc[u]; E.mx = ra[u].x; E.my = ra[u].y; E.i00 = rb[u].x; E.i01 = rb[u].y; E.i11 = rc[u];
+        const u64 cb = (u64)__double_as_longlong(rc[u].y);
+        CellEntry E; E.cent = make_float2(__uint_as_float((unsigned)cb), __uint_as_float((unsigned)(cb >> 32)));
+        E.mx = ra[u].x; E.my = ra[u].y; E.i00 = rb[u].x; E.i01 = rb[u].y; E.i11 = rc[u].x;
         ent[nx[u]] = E;
       }
     }
@@ -422,6 +429,8 @@ __device__ __noinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool, 
 // fill_window and the helpers use.  Uses the LDS pool as scratch (before the window is staged).
 // Returns false (bitmap still produced, scratch copy not written) when the scan is too large for it.
 constexpr int kSortMax = 20000;             // LDS room for one word per point; point numbers < 2^15
+constexpr int kSortRegs = 10 * kBlock;      // order_scan_regs: the scan in registers, two words per point in LDS beside the counters
+static_assert(((kRegionCells + 1 + 3) & ~3) * 4 + 2 * kSortRegs * 4 <= kPoolBytes, "counters + entries + places in the LDS pool");
 template <bool SSE>
 __device__ __noinline__ bool sort_points(const MapView &M, const Tf32 &T0, const float2 *__restrict__ scan,
                                             int n, Lds &L, uint4 *pool, float2 *__restrict__ sp,
@@ -523,6 +532,197 @@ __device__ __noinline__ bool sort_points(const MapView &M, const Tf32 &T0, const
   }
   __syncthreads();
   return true;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves only (row shifts with zero fill, then the row totals
+// carried into the next rows): no LDS round trips.
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned x) {
+#define NDT_DPP_ADD(CTRL, ROWS) x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xF, true)
+  NDT_DPP_ADD(0x111, 0xF);     // row_shr:1
+  NDT_DPP_ADD(0x112, 0xF);     // row_shr:2
+  NDT_DPP_ADD(0x114, 0xF);     // row_shr:4
+  NDT_DPP_ADD(0x118, 0xF);     // row_shr:8
+  NDT_DPP_ADD(0x142, 0xA);     // row_bcast15: the total of rows 0 / 2 into rows 1 / 3
+  NDT_DPP_ADD(0x143, 0xC);     // row_bcast31: the total of rows 0 + 1 into rows 2, 3
+#undef NDT_DPP_ADD
+  return x;
+}
+
+// Owner: optimiser start + window geometry + spatial order of a scan of at most PER * kBlock points in ONE routine that
+// keeps the scan in registers (round 3; compute_region + sort_points below remain for longer scans).  The separate
+// routines read the scan from memory four times -- bounding box, histogram, scatter, and a gather by point number in the
+// ranking phase, a few loads in flight each, every round a trip to L2 -- and every phase was a chain of dependent LDS
+// round trips between two barriers: 33 us of the 50 us a scan's set-up took.  Here every thread loads its PER points
+// once (all loads in flight; the counters are cleared and lane 0 sets the optimiser state up while they travel), every
+// thread derives the window geometry itself (no broadcast through LDS), a thread's run of cell counters is read into
+// registers once for both the marked-cell bitmap and the offsets, and in the last phase each thread ranks ITS OWN points
+// inside their cells -- the PER searches interleaved, so that their LDS reads pipeline -- and stores them from the
+// registers: no gather.  Same order as sort_points (window cell, then input order), same bitmap.
+template <bool SSE, int PER>
+__device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &P, const double *__restrict__ init,
+                                             const float2 *__restrict__ scan, int n, Lds &L, uint4 *pool,
+                                             float2 *__restrict__ sp, u64 *stamps = nullptr, u64 t0s = 0) {
+  // The LDS pipe takes one wave instruction every ~4 cycles whatever its width (tools/repro/rates.hip), and these phases
+  // are nothing but LDS traffic: counters, entries and places are moved 16 bytes at a time.
+  constexpr int kRun = 20;                                             // counters per thread: five 16-byte words
+  constexpr int kHistWords = (kRegionCells + 1 + 3) & ~3;              // ncell + 1 counters (last: outside the window), padded
+  static_assert(kRun * kBlock >= kHistWords && kRun % 4 == 0, "every counter belongs to a thread's run");
+  float2 pt[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) pt[u] = gld_f2(scan + min((int)threadIdx.x + u * kBlock, n - 1));
+  // ... while the first touch of the scan is on its way
+  unsigned *wmap = reinterpret_cast<unsigned *>(L.wpart);
+  unsigned *hist = reinterpret_cast<unsigned *>(pool);
+  unsigned *idx = hist + kHistWords;                                   // n entries (cell << 15 | point number)
+  unsigned *inv = idx + kSortRegs;                                     // place of point i in the ordered copy
+#pragma unroll
+  for (int k = 0; k < (kHistWords / 4 + kBlock - 1) / kBlock; ++k) {
+    const int i = (int)threadIdx.x + k * kBlock;
+    if (i < kHistWords / 4) pool[i] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  if (threadIdx.x < kRegionCells / 32) wmap[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) {
+    init_state(L.S, P, init, (double)n);
+    L.sbox[0] = INT_MAX; L.sbox[1] = INT_MAX; L.sbox[2] = INT_MIN; L.sbox[3] = INT_MIN;
+  }
+  __syncthreads();
+  NDT_STAMP(stamps, t0s, 0);
+  const Tf32 T0 = L.S.T;
+  // voxel coordinates at the first pose
+  auto vox = [&](float2 p, int &ix, int &iy) {
+    float xt, yt;
+    tf_apply_t<SSE>(T0, p.x, p.y, xt, yt);
+    const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
+    ix = (int)fx - M.min_bx; iy = (int)fy - M.min_by;
+    return finite2(xt, yt);
+  };
+  {
+    int mnx = INT_MAX, mny = INT_MAX, mxx = INT_MIN, mxy = INT_MIN;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      int ix, iy;
+      if (vox(pt[u], ix, iy) && (int)threadIdx.x + u * kBlock < n) {
+        mnx = ix < mnx ? ix : mnx; mxx = ix > mxx ? ix : mxx;
+        mny = iy < mny ? iy : mny; mxy = iy > mxy ? iy : mxy;
+      }
+    }
+    mnx = wave_min_i(mnx); mny = wave_min_i(mny); mxx = wave_max_i(mxx); mxy = wave_max_i(mxy);
+    if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
+      atomicMin(&L.sbox[0], mnx); atomicMin(&L.sbox[1], mny); atomicMax(&L.sbox[2], mxx); atomicMax(&L.sbox[3], mxy);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) region_from_bbox(M, L);
+  __syncthreads();
+  NDT_STAMP(stamps, t0s, 1);
+  const Region r = L.RG;
+  const int ncell = r.rw * r.rh;
+  int key[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    key[u] = -1;
+    if ((int)threadIdx.x + u * kBlock < n) {
+      int ix, iy;
+      const bool fin = vox(pt[u], ix, iy);
+      const int lx = ix - r.x0, ly = iy - r.y0;
+      key[u] = (!fin || lx < 0 || lx >= r.rw || ly < 0 || ly >= r.rh) ? ncell : ly * r.rw + lx;
+      atomicAdd(&hist[key[u]], 1u);
+    }
+  }
+  __syncthreads();
+  NDT_STAMP(stamps, t0s, 2);
+  // A thread's run of kRun counters, read once (counters past ncell are zero): its bits of the marked-cell bitmap (the
+  // run touches at most two words) and its part of the exclusive scan (DPP scan over the wave, the waves' totals through LDS).
+  {
+    const int c0 = (int)threadIdx.x * kRun;
+    const bool live = c0 < kHistWords;
+    unsigned cnt[kRun];
+#pragma unroll
+    for (int k = 0; k < kRun / 4; ++k) {
+      const uint4 q = live ? pool[(c0 >> 2) + k] : make_uint4(0u, 0u, 0u, 0u);
+      cnt[4 * k] = q.x; cnt[4 * k + 1] = q.y; cnt[4 * k + 2] = q.z; cnt[4 * k + 3] = q.w;
+    }
+    unsigned mine = 0; u64 bits = 0;
+#pragma unroll
+    for (int k = 0; k < kRun; ++k) { mine += cnt[k]; if (cnt[k] != 0u && c0 + k < ncell) bits |= 1ull << k; }
+    bits <<= (c0 & 31);
+    if ((unsigned)bits) atomicOr(&wmap[c0 >> 5], (unsigned)bits);
+    if ((unsigned)(bits >> 32)) atomicOr(&wmap[(c0 >> 5) + 1], (unsigned)(bits >> 32));
+    const unsigned incl = wave_incl_scan(mine);
+    if ((threadIdx.x & 63) == 63) L.swave[threadIdx.x >> 6] = (int)incl;
+    __syncthreads();
+    unsigned run = incl - mine;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += (unsigned)L.swave[w];
+    if (live) {
+#pragma unroll
+      for (int k = 0; k < kRun / 4; ++k) {
+        uint4 q;
+        q.x = run; run += cnt[4 * k]; q.y = run; run += cnt[4 * k + 1]; q.z = run; run += cnt[4 * k + 2]; q.w = run; run += cnt[4 * k + 3];
+        pool[(c0 >> 2) + k] = q;
+      }
+    }
+  }
+  __syncthreads();
+  NDT_STAMP(stamps, t0s, 3);
+  // scatter (cell, point number) packed in one word; afterwards hist[c] = end of cell c
+#pragma unroll
+  for (int u = 0; u < PER; ++u)
+    if (key[u] >= 0) idx[atomicAdd(&hist[key[u]], 1u)] = ((unsigned)key[u] << 15) | (unsigned)((int)threadIdx.x + u * kBlock);
+  __syncthreads();
+  NDT_STAMP(stamps, t0s, 4);
+  // Input order inside a cell (the atomics above arrive in any order).  Ranking is done by POSITION -- consecutive lanes
+  // on consecutive entries, i.e. mostly on the same cell: equal trip counts, broadcast reads (by point, a wave's 64
+  // random points made every lane wait for the densest cell among them: 23 us) -- four entries of the cell per LDS read.
+  // The place of point i goes to inv[i]; the thread that holds point i in a register puts it there in an LDS image of
+  // the ordered copy (the counters and entries are dead by then), which goes to memory in coalesced 16-byte stores:
+  // no gather from memory, no scattered 8-byte stores (10k of those per workgroup took 13 us to drain).
+  {
+    const uint4 *idx4 = reinterpret_cast<const uint4 *>(idx);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int pp = (int)threadIdx.x + u * kBlock;
+      if (pp < n) {
+        const unsigned v = idx[pp];
+        const int k = (int)(v >> 15);
+        const int s0 = k ? (int)hist[k - 1] : 0, s1 = (int)hist[k];
+        int rank = 0;
+        for (int q = s0 >> 2; q <= (s1 - 1) >> 2; ++q) {                 // aligned quads covering [s0, s1)
+          const uint4 e = idx4[q];
+          const int a = q << 2;
+          rank += (a >= s0 && a < s1 && e.x < v) ? 1 : 0;
+          rank += (a + 1 >= s0 && a + 1 < s1 && e.y < v) ? 1 : 0;
+          rank += (a + 2 >= s0 && a + 2 < s1 && e.z < v) ? 1 : 0;
+          rank += (a + 3 >= s0 && a + 3 < s1 && e.w < v) ? 1 : 0;
+        }
+        inv[v & 0x7FFFu] = (unsigned)(s0 + rank);
+      }
+    }
+  }
+  NDT_STAMP(stamps, t0s, 11);
+  __syncthreads();
+  NDT_STAMP(stamps, t0s, 12);
+  unsigned place[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) place[u] = key[u] >= 0 ? inv[(int)threadIdx.x + u * kBlock] : 0u;
+  float2 *stage = reinterpret_cast<float2 *>(pool);                    // n points over the dead counters and entries
+  static_assert(kSortRegs * 8 <= (kHistWords + kSortRegs) * 4, "the LDS image of the ordered copy must not reach the places");
+#pragma unroll
+  for (int u = 0; u < PER; ++u) if (key[u] >= 0) stage[place[u]] = pt[u];
+  __syncthreads();
+  NDT_STAMP(stamps, t0s, 13);
+  {
+    const float4 *st4 = reinterpret_cast<const float4 *>(pool);
+    float4 *sp4 = reinterpret_cast<float4 *>(sp);                      // (scratch slots start at even point numbers? see below)
+    const bool aligned = (reinterpret_cast<size_t>(sp) & 15) == 0;
+    if (aligned) {
+      for (int i = threadIdx.x; i < n / 2; i += kBlock) sp4[i] = st4[i];
+      if (threadIdx.x == 0 && (n & 1)) sp[n - 1] = stage[n - 1];
+    } else {
+      for (int i = threadIdx.x; i < n; i += kBlock) sp[i] = stage[i];
+    }
+  }
+  __syncthreads();
 }
 
 // Sum of 12 per-lane values over the 64 lanes of a wave in a fixed order: a butterfly in which every exchange also
@@ -644,7 +844,7 @@ __device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_i
   M.gw = (int)uniform_u((unsigned)L.M.gw); M.gh = (int)uniform_u((unsigned)L.M.gh);
   M.cent = uniform_p(L.M.cent); M.rec = uniform_p(L.M.rec); M.occ = uniform_p(L.M.occ);
   M.pt_start = uniform_p(L.M.pt_start); M.pts = uniform_p(L.M.pts);
-  M.d1 = uniform_d(L.M.d1); M.d2 = uniform_d(L.M.d2);
+  M.d1 = uniform_d(L.M.d1); M.d2 = uniform_d(L.M.d2); M.e_hi = uniform_d(L.M.e_hi);
   Region R;
   R.x0 = (int)uniform_u((unsigned)L.RG.x0); R.y0 = (int)uniform_u((unsigned)L.RG.y0);
   R.rw = (int)uniform_u((unsigned)L.RG.rw); R.rh = (int)uniform_u((unsigned)L.RG.rh);
@@ -758,8 +958,11 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     ScanCtl *C = ctl + b;
     u64 *mytot = utot + (size_t)b * kUnits * kUnitWords;
     __syncthreads();
+    // scans that fit the register-resident set-up (order_scan_regs) get their optimiser state set up in there, under the
+    // latency of the scan's first touch
+    const bool reg_path = n > 0 && sorted != nullptr && n <= kSortRegs;
     if (threadIdx.x == 0) {
-      init_state(L.S, L.P, inits + 3 * (size_t)b, (double)n);
+      if (!reg_path) init_state(L.S, L.P, inits + 3 * (size_t)b, (double)n);
       if (trace_rows) trace_rows[b] = 0;
       if (n <= 0) { L.S.phase = PH_DONE; L.S.converged = 0; }
     }
@@ -769,13 +972,19 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     const u64 t0s = kProf ? wall_clock64() : 0;
     if (n > 0) {
       const u64 q0 = kProf ? wall_clock64() : 0;
-      NDT_STAMP(stamps, t0s, 0);
+      if (!reg_path) NDT_STAMP(stamps, t0s, 0);
       // scratch copy: at the scan's own offsets, or (every match uses scan 0) one slot per match
       float2 *sp = sorted ? (shared_scan ? sorted + (size_t)b * (size_t)n : sorted + o0) : nullptr;
-      compute_region<SSE>(L.M, L.S.T, scan, n, L);
-      const u64 q1 = kProf ? wall_clock64() : 0;
-      NDT_STAMP(stamps, t0s, 1);
-      if (sort_points<SSE>(L.M, L.S.T, scan, n, L, pool, sp, stamps, t0s)) pts = sp;
+      u64 q1 = 0;
+      if (reg_path) {
+        order_scan_regs<SSE, kSortRegs / kBlock>(L.M, L.P, inits + 3 * (size_t)b, scan, n, L, pool, sp, stamps, t0s); pts = sp;
+      } else {
+        compute_region<SSE>(L.M, L.S.T, scan, n, L);
+        q1 = kProf ? wall_clock64() : 0;
+        NDT_STAMP(stamps, t0s, 1);
+        if (sort_points<SSE>(L.M, L.S.T, scan, n, L, pool, sp, stamps, t0s)) pts = sp;
+      }
+      if (kProf && q1 == 0) q1 = wall_clock64();
       NDT_STAMP(stamps, t0s, 5);
       const u64 q2 = kProf ? wall_clock64() : 0;
       if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
@@ -932,6 +1141,11 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (kProf && prof) { tt1 = wall_clock64(); }
         if (lane == 0) advance(L.S, L.P, L.M, L.tot, tr, trace_cap, trace_rows ? trace_rows + b : nullptr);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int need_tf = L.S.need_tf;                       // (uniform: one LDS word)
+        if (need_tf && lane < 2) trial_transforms(L.S, L.P, lane, need_tf);
       }
       // meanwhile another wave fetches the number of registered helpers for the next pass
       if (threadIdx.x == 64 && allow_helpers) L.sflag[1] = (int)rd32_fresh(&C->ready);

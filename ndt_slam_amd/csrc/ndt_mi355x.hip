@@ -188,6 +188,17 @@ void gauss_constants(const ndt_params &p, double *d1, double *d2) {
   *d2 = -2.0 * std::log((-std::log(c1 * std::exp(-0.5) + c2) - d3) / *d1);
 }
 
+// Largest double e with fl(d2 * e) <= 1 (d2 > 0): updateDerivatives drops a pair when d2 e > 1, d2 e < 0 or NaN; e = exp(..)
+// is never negative, so the check is `e > e_hi` (ndt_point.hip.h).  Plain fp64 products, as the device would form them.
+double pair_check_threshold(double d2) {
+  if (d2 != d2 || d2 == 0.0) return INFINITY;
+  if (d2 < 0.0) return -1.0;                       // every e > 0 gives d2 e < 0; e == 0 adds nothing either way
+  volatile double e = 1.0 / d2, pr;
+  for (int i = 0; i < 64; ++i) { pr = d2 * e; if (pr <= 1.0) break; e = std::nextafter((double)e, 0.0); }
+  for (int i = 0; i < 64; ++i) { const double up = std::nextafter((double)e, INFINITY); pr = d2 * up; if (!(pr <= 1.0)) break; e = up; }
+  return e;
+}
+
 // exp table 2^(j/64), correctly rounded, uploaded once per device
 int upload_exp_table(ndt_ctx *ctx);
 
@@ -423,6 +434,16 @@ int ndt_kernel_timing(ndt_ctx *c, int back, float *match_ms, float *fitness_ms) 
   return NDT_OK;
 }
 
+int ndt_launch_interval(ndt_ctx *c, int back, float *interval_ms) {
+  if (!c || !interval_ms || back < 0 || back + 1 >= ndt_ctx::kTimeRing || (unsigned long long)(back + 1) >= c->launches)
+    return fail(c, NDT_E_ARG, "ndt_launch_interval: no such pair of launches in the ring");
+  hipEvent_t *e1 = c->ev_ring + 3 * ((c->launches - 1 - (unsigned long long)back) % ndt_ctx::kTimeRing);
+  hipEvent_t *e0 = c->ev_ring + 3 * ((c->launches - 2 - (unsigned long long)back) % ndt_ctx::kTimeRing);
+  HIP_TRY(c, hipEventSynchronize(e1[0]));
+  HIP_TRY(c, hipEventElapsedTime(interval_ms, e0[0], e1[0]));
+  return NDT_OK;
+}
+
 int ndt_ctx_wait_launch(ndt_ctx *c, int back, void *stream) {
   if (!c || back < 0 || back >= ndt_ctx::kTimeRing || (unsigned long long)back >= c->launches)
     return fail(c, NDT_E_ARG, "ndt_ctx_wait_launch: no such launch in the ring");
@@ -526,6 +547,7 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   V.min_bx = G.min_bx; V.min_by = G.min_by; V.div_x = G.div_x; V.div_y = G.div_y; V.gw = G.gw; V.gh = G.gh;
   V.cent = m->cent; V.rec = m->rec; V.occ = m->occ; V.pt_start = start; V.pts = m->pts;
   gauss_constants(*prm, &V.d1, &V.d2);
+  V.e_hi = pair_check_threshold(V.d2);
   m->info.min_bx = G.min_bx; m->info.min_by = G.min_by; m->info.div_x = G.div_x; m->info.div_y = G.div_y;
   m->info.n_points = n;
   return NDT_OK;

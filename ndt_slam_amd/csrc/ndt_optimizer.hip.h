@@ -119,9 +119,25 @@ __device__ __forceinline__ void set_trial(AlignState &S, const OptParams &P, boo
   S.xt[0] = S.p[0] + S.dir[0] * S.a_t;
   S.xt[1] = S.p[1] + S.dir[1] * S.a_t;
   S.xt[2] = S.p[2] + S.dir[2] * S.a_t;
-  S.T = tf_from_p(S.xt);
-  angle_cs(P.snap_thresh, S.xt[2], S.cj, S.sj);
-  if (refresh_h || !P.stale_h_ang) { S.ch = S.cj; S.sh = S.sj; }
+  S.need_tf = 1 | ((refresh_h || !P.stale_h_ang) ? 2 : 0);      // -> trial_transforms
+}
+
+// The two sincos of a new trial -- the float32 matrix (of the float32 yaw) and the fp64 angle terms of J_E / H_E -- are
+// a few hundred dependent instructions each on the one lane that runs the optimiser, behind every pass with the whole
+// workgroup waiting: lanes 0 and 1 of the wave compute them side by side (same code, different argument).
+__device__ __noinline__ void trial_transforms(AlignState &S, const OptParams &P, int lane, int need) {
+  const double yaw = S.xt[2];
+  const double arg = lane == 0 ? (double)(float)yaw : yaw;
+  double sn, cs;
+  sincos(arg, &sn, &cs);
+  if (lane == 0) {
+    S.T.c = (float)cs; S.T.s = (float)sn; S.T.tx = (float)S.xt[0]; S.T.ty = (float)S.xt[1];
+    S.need_tf = 0;
+  } else {
+    if (fabs(yaw) < P.snap_thresh) { cs = 1.0; sn = 0.0; }
+    S.cj = cs; S.sj = sn;
+    if (need & 2) { S.ch = cs; S.sh = sn; }
+  }
 }
 
 // Start (or finish) outer iterations until a derivative pass is needed or the match is done.
@@ -259,6 +275,7 @@ __device__ __noinline__ void init_state(AlignState &S, const OptParams &P, const
   angle_cs(P.snap_thresh, S.p[2], S.cj, S.sj);
   S.ch = S.cj; S.sh = S.sj;
   S.score = 0.0;
+  S.need_tf = 0;
   S.phase = PH_INIT;
 }
 

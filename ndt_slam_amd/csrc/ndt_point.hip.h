@@ -34,13 +34,16 @@ __device__ __forceinline__ double exp_neg(double x, const double *__restrict__ t
   x = fmax(x, -800.0);
   const double t = rint(x * 92.332482616893657);            // 64 / ln 2
   const int n = (int)t;
+  const double sc = tab[n & 63];
+#ifndef NDT_NO_EXP_SCHED
+  __builtin_amdgcn_sched_barrier(0);                        // issue the table read BEFORE the polynomial (the scheduler put it behind: a full LDS latency exposed per pair)
+#endif
   double r = __builtin_fma(-t, 0x1.62e42fefa0000p-7, x);    // ln2/64, high part (exact product)
   r = __builtin_fma(-t, 0x1.cf79abc9e3b3ap-46, r);          // low part
   double p = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);
   p = __builtin_fma(r, p, 1.0 / 6.0);
   p = __builtin_fma(r, p, 0.5);
   p = __builtin_fma(p, r * r, r);                           // exp(r) - 1
-  const double sc = tab[n & 63];
   return ldexp(__builtin_fma(sc, p, sc), n >> 6);
 }
 
@@ -79,15 +82,17 @@ __device__ __forceinline__ CellRec load_rec_global(const MapView &M, size_t base
 struct PointAcc { double se, a0, a1, b00, b01, b11; };
 
 // one (point, voxel) pair
-__device__ __forceinline__ void accumulate_pair(double d2, double nd2, double nd2h, const double *__restrict__ etab,
+// updateDerivatives' error check `d2 e > 1 || d2 e < 0 || NaN` as one comparison: e >= 0 always (exp_neg), so for d2 > 0
+// the pair is dropped exactly when e > e_hi, e_hi = the largest double with fl(d2 * e_hi) <= 1 (found on the host,
+// MapView::e_hi; -1 when d2 < 0: every pair with e > 0 is dropped, +inf when d2 is 0 or NaN).
+__device__ __forceinline__ void accumulate_pair(double e_hi, double nd2, double nd2h, const double *__restrict__ etab,
                                                 double XT, double YT, const CellRec &c, PointAcc &S) {
   const double q0 = XT - c.mx, q1 = YT - c.my;
   const double u0 = __builtin_fma(c.i01, q1, c.i00 * q0);      // Sigma^-1 q
   const double u1 = __builtin_fma(c.i11, q1, c.i01 * q0);
   const double m = __builtin_fma(q1, u1, q0 * u0);
   double e = exp_neg(nd2h * m, etab);                          // (-d2 m) / 2, the halving is exact
-  const double e2 = d2 * e;
-  if (e2 > 1.0 || e2 < 0.0) e = 0.0;                           // updateDerivatives error check
+  if (e > e_hi) e = 0.0;                                       // updateDerivatives error check
   const double v0 = nd2 * u0, v1 = nd2 * u1;
   S.se += e;
   S.a0 = __builtin_fma(e, u0, S.a0);
@@ -126,17 +131,17 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
                                            float y, double cj, double sj, double ch, double sh, Acc &A) {
   float xt, yt;
   tf_apply_t<SSE>(T, x, y, xt, yt);
-  const bool fin = finite2(xt, yt);
-  const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);
+  const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);     // (NaN -> -1e9: outside every window and grid)
   const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
-  const int ix = (int)fx - M.min_bx, iy = (int)fy - M.min_by;
-  const bool ingrid = fin & (ix >= -1) & (ix <= M.div_x) & (iy >= -1) & (iy <= M.div_y);
   const Region &R = W.R;
-  const int lx = ix - R.x0, ly = iy - R.y0;
-  const bool inwin = ingrid & (lx >= 1) & (lx < R.rw - 1) & (ly >= 1) & (ly < R.rh - 1);
+  // window coordinates.  The window lies inside the padded grid (compute_region clips it), so "3x3 neighbourhood inside
+  // the window" implies "inside the grid" and "finite": one unsigned comparison per axis decides the fast path.
+  const int lx = (int)fx - (M.min_bx + R.x0), ly = (int)fy - (M.min_by + R.y0);
+  const bool inwin = ((unsigned)(lx - 1) < (unsigned)max(R.rw - 2, 0)) & ((unsigned)(ly - 1) < (unsigned)max(R.rh - 2, 0));
   // LDS probes with clamped indices (results dropped when !inwin)
   const int clx = min(max(lx, 1), max(R.rw - 2, 1)), cly = min(max(ly, 1), max(R.rh - 2, 1));
-  const unsigned short *srow = W.slot + (cly - 1) * R.rw + (clx - 1);
+  const unsigned short *srow = W.slot + (__mul24(cly - 1, R.rw) + (clx - 1));
+  const int rw3 = R.rw - 3;                    // slot of neighbour k = 3 r + q: srow[r * rw + q] = srow[r * (rw - 3) + k]
   unsigned mask = 0;
   float lowx = INFINITY;                       // -inf <=> one of the nine voxels is occupied but not resident
 #pragma unroll
@@ -157,16 +162,18 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
     do {
       const int k = __builtin_ctz(mask);
       mask &= mask - 1;
-      const int r = (k * 11) >> 5, q = k - 3 * r;
-      const CellEntry &E = W.ent[srow[r * R.rw + q]];
+      const int r = __mul24(k, 11) >> 5;                       // k / 3 for k in [0, 9)
+      const CellEntry &E = W.ent[srow[__mul24(r, rw3) + k]];
       CellRec c; c.mx = E.mx; c.my = E.my; c.i00 = E.i00; c.i01 = E.i01; c.i11 = E.i11;
-      accumulate_pair(M.d2, nd2, nd2h, etab, XT, YT, c, S);
+      accumulate_pair(M.e_hi, nd2, nd2h, etab, XT, YT, c, S);
     } while (mask);
     finish_point(x, y, cj, sj, ch, sh, S, A);
     return;
   }
-  if (!ingrid) return;
   // slow path: global centroid grid and record array
+  const int ix = lx + R.x0, iy = ly + R.y0;
+  const bool ingrid = finite2(xt, yt) & (ix >= -1) & (ix <= M.div_x) & (iy >= -1) & (iy <= M.div_y);
+  if (!ingrid) return;
   const size_t base = (size_t)(iy + 1) * M.gw + (ix + 1);     // padded coords of (ix-1, iy-1)
   const float2 *grow = M.cent + base;
   mask = 0;
@@ -182,7 +189,7 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
   do {
     const int k = __builtin_ctz(mask);
     mask &= mask - 1;
-    accumulate_pair(M.d2, nd2, nd2h, etab, XT, YT, load_rec_global(M, base, k), S);
+    accumulate_pair(M.e_hi, nd2, nd2h, etab, XT, YT, load_rec_global(M, base, k), S);
   } while (mask);
   finish_point(x, y, cj, sj, ch, sh, S, A);
 }

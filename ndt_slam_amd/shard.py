@@ -91,11 +91,16 @@ def best_hypothesis_t(scores, global_index):
     hypotheses, `global_index` the int64 tensor of their global numbers (ascending), both on the device the process
     group communicates from.  Returns (best score, its global index) as 1-element tensors on every rank; ties go
     to the lowest global index.  Two all-reduces of 8 bytes."""
-    best, k = torch.max(scores, dim=0)
+    if scores.numel() == 0:                          # an empty shard takes part in the collectives with -inf
+        best = torch.full((), float("-inf"), dtype=scores.dtype, device=scores.device)
+        k = None
+    else:
+        best, k = torch.max(scores, dim=0)
     t = best.reshape(1).clone()
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     big = torch.full((1,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=scores.device)
-    cand = torch.where(best.reshape(1) == t, global_index[k].reshape(1), big)
+    mine = global_index[k].reshape(1) if k is not None else big
+    cand = torch.where(best.reshape(1) == t, mine, big)
     dist.all_reduce(cand, op=dist.ReduceOp.MIN)
     return t, cand
 

@@ -1,6 +1,7 @@
-"""The N > 1 path on CPU: world_size-2 `gloo` processes shard a batch, match their shards (with the
+"""The N > 1 path on CPU: world_size 2 / 4 / 8 `gloo` processes shard a batch, match their shards (with the
 CPU oracle standing in for the kernel -- this test is about the scatter / gather bookkeeping) and
-gather the result records; rank 0 must end up with exactly the single-process results."""
+gather the result records; rank 0 must end up with exactly the single-process results.  The batch (7 scans) is
+never divisible by the world size, and with 8 ranks the last shard is EMPTY."""
 import os
 import socket
 
@@ -50,9 +51,9 @@ def _worker(rank, world, port, outdir):
     lo, hi = shard.shard_bounds(B, world, rank)
     assert len(ini) == hi - lo and len(of) == hi - lo + 1 and int(of[0]) == 0 and int(of[-1]) == len(sc)
     sc, of, ini = sc.numpy(), of.numpy().astype(np.uint64), ini.numpy()      # (device tensors on the GPU box: data_ptr())
-    res = om.align_batch(sc, of, ini)
-    pad = 4 - len(res)                                            # equal-size records for gather
-    buf = np.zeros(4 * O.RESULT_DTYPE.itemsize, np.uint8)
+    res = om.align_batch(sc, of, ini) if hi > lo else np.zeros(0, O.RESULT_DTYPE)
+    most = shard.shard_bounds(B, world, 0)[1]                     # the largest shard: equal-size records for gather
+    buf = np.zeros(most * O.RESULT_DTYPE.itemsize, np.uint8)
     buf[:len(res) * O.RESULT_DTYPE.itemsize] = np.frombuffer(res.tobytes(), np.uint8)
     got = shard.gather_results(torch.from_numpy(buf), dst=0)
     best = shard.best_hypothesis(res["trans_prob"], shard.shard_bounds(B, world, rank)[0])
@@ -74,7 +75,8 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_two_rank_scatter_match_gather(tmp_path, oracle):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_scatter_match_gather(tmp_path, oracle, world):
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     assert open(os.path.join(str(tmp_path), "ok")).read() == "1"

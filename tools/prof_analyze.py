@@ -31,6 +31,7 @@ print("setup phases us (means): region %.1f sort %.1f fill %.1f (marking %.1f, n
     (raw2[:, 6] >> 32).mean() * 0.01, (raw2[:, 6] & 0xFFFFFFFF).mean() * 0.01,
     (raw2[:, 7] >> 32).mean() * 0.01, ((raw2[:, 7] >> 16) & 0xFFFF).mean() * 0.01, (raw2[:, 7] & 0xFFFF).mean() * 0.01))
 names = ["init_state", "region", "sort:histogram", "sort:scan", "sort:scatter", "sort:rank+copy", "publish", "fill:occupancy", "fill:dilate", "fill:number", "fill:records"]
+print("extra stamps 11..15 (absolute us since the scan was taken):", m_extra if (m_extra := stamps.mean(0)[11:16].round(1).tolist()) else "")
 m = stamps.mean(0)
 print("setup stamps us (mean, cumulative -> delta):")
 prev = 0.0
