@@ -114,7 +114,8 @@ struct alignas(128) ScanCtl {
   u32 passes;        //         passes the owner has run so far (helpers go where most were needed)
   u32 ready;         //         helpers whose window is staged; rank = order of registration
   u32 use_sorted;    //         1: passes read the scan from the sorted scratch copy
-  int pad2_[22];
+  u32 claimed;       //         1: a workgroup owns this scan (compare-and-swap; see "claims" in the kernel)
+  int pad2_[21];
 };
 static_assert(sizeof(ScanCtl) == 256, "ScanCtl is two 128-byte lines");
 
@@ -163,6 +164,7 @@ struct Lds {
   unsigned long long hword;        // helper: epoch word seen by wave 0
   int hrank;                       // helper: order of registration on its scan
   int jnext;                       // units of the open segment handed out so far
+  int steal;                       // helper search: nearest scan nobody has claimed yet (its workgroup is not resident)
   unsigned diag[2];                // diagnostic: ticks of fill_window's first two phases
   int clipped;                     // owner: the scan's voxel bounding box did not fit the window
   // what a pass needs besides PP and RG, read by pass_units (a separate function: see there)
@@ -948,7 +950,15 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
 
   // =========================== owner of scans blockIdx.x, + gridDim.x, ... ===========================
   // scans are taken from a queue: the first gridDim.x by workgroup number, the rest in the order
-  // workgroups become free (results do not depend on who owns which scan)
+  // workgroups become free (results do not depend on who owns which scan).
+  // Claims (round 3): the first gridDim.x scans belong to the workgroups of the same number only once those have won a
+  // compare-and-swap on the scan's `claimed` word.  A launch is NOT guaranteed one resident workgroup per CU -- another
+  // queue's kernel may hold CUs -- and a workgroup that is not resident cannot start the scan its number stands for; the
+  // resident ones used to finish their own scans and then poll that scan's control word for as long as the foreign kernel
+  // ran (tests/test_gpu_robustness.py: 20 ms).  Now a workgroup that has used the queue up first looks for a scan nobody
+  // has claimed and takes it over; the late workgroup finds its scan taken and moves on: no wait in the kernel depends
+  // on a workgroup that is not running.  (Scans of the queue are handed out by a counter to workgroups that are running.)
+  int preclaimed = -1;
   for (int b = blockIdx.x; b < B && !aborted;) {
     const u64 o0 = shared_scan ? offsets[0] : offsets[b];
     const u64 o1 = shared_scan ? offsets[1] : offsets[b + 1];
@@ -962,11 +972,24 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     // latency of the scan's first touch
     const bool reg_path = n > 0 && sorted != nullptr && n <= kSortRegs;
     if (threadIdx.x == 0) {
-      if (!reg_path) init_state(L.S, L.P, inits + 3 * (size_t)b, (double)n);
-      if (trace_rows) trace_rows[b] = 0;
-      if (n <= 0) { L.S.phase = PH_DONE; L.S.converged = 0; }
+      u32 expect = 0u;
+      const bool won = !allow_helpers || b >= (int)gridDim.x || b == preclaimed ||
+                       __hip_atomic_compare_exchange_strong(&C->claimed, &expect, 1u, NDT_RLX, NDT_RLX, NDT_AGENT);
+      L.sflag[3] = won ? 1 : 0;
+      if (won) {
+        if (!reg_path) init_state(L.S, L.P, inits + 3 * (size_t)b, (double)n);
+        if (trace_rows) trace_rows[b] = 0;
+        if (n <= 0) { L.S.phase = PH_DONE; L.S.converged = 0; }
+      }
     }
     __syncthreads();
+    if (!L.sflag[3]) {                        // taken over by another workgroup while this one was not resident: next scan
+      __syncthreads();
+      if (threadIdx.x == 0) L.sflag[3] = (int)gridDim.x + (int)__hip_atomic_fetch_add(&hdr->next, 1u, NDT_RLX, NDT_AGENT);
+      __syncthreads();
+      b = L.sflag[3];
+      continue;
+    }
     const float2 *pts = scan;
     u64 *const stamps = (kProf && prof) ? prof + 16 * (size_t)B + 16 * (size_t)b : nullptr;
     const u64 t0s = kProf ? wall_clock64() : 0;
@@ -1192,11 +1215,33 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         p2[0] = a_n; p2[1] = a_pro; p2[2] = a_own; p2[3] = a_wait; p2[4] = a_comb; p2[5] = a_adv;
       }
     }
-      // next scan of the batch, if any
+      // next scan of the batch, if any: from the queue; once that is used up, a scan nobody has claimed (see "Claims")
     __syncthreads();
-    if (threadIdx.x == 0) L.sflag[3] = (int)gridDim.x + (int)__hip_atomic_fetch_add(&hdr->next, 1u, NDT_RLX, NDT_AGENT);
+    if (threadIdx.x == 0) { L.sflag[3] = (int)gridDim.x + (int)__hip_atomic_fetch_add(&hdr->next, 1u, NDT_RLX, NDT_AGENT); L.steal = INT_MAX; }
     __syncthreads();
     b = L.sflag[3];
+    if (b >= B && allow_helpers && !aborted) {
+      const int first = min(B, (int)gridDim.x);
+      for (int k = threadIdx.x; k < first; k += kBlock)
+        if (ld32(&ctl[k].claimed) == 0u) atomicMin(&L.steal, k);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int got = B;
+        for (int tries = 0; tries < 4 && L.steal != INT_MAX && got == B; ++tries) {   // lost a race: the next free one, if any
+          u32 expect = 0u;
+          if (__hip_atomic_compare_exchange_strong(&ctl[L.steal].claimed, &expect, 1u, NDT_RLX, NDT_RLX, NDT_AGENT)) got = L.steal;
+          else {
+            int nx = INT_MAX;
+            for (int k = L.steal + 1; k < first; ++k) if (ld32(&ctl[k].claimed) == 0u) { nx = k; break; }
+            L.steal = nx;
+          }
+        }
+        L.sflag[3] = got;
+      }
+      __syncthreads();
+      b = L.sflag[3];
+      preclaimed = b;
+    }
   }
 
   // ============================================ helper ============================================
@@ -1215,7 +1260,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     for (int k = threadIdx.x; k < B; k += kBlock) {
       int b = start + k; if (b >= B) b -= B;
       const u32 ep = (u32)(rd64_fresh(&ctl[b].ticket) >> 32);
-      if (ep == 0u) { L.sflag[2] = 1; continue; }          // not open yet (owner still setting up): may need help later
+      if (ep == 0u) { L.sflag[2] = 1; continue; }          // not open yet (its owner is setting up, or a workgroup that runs out of work will claim it): may need help later
       if (ep == kEpochDone) continue;
       const u32 h = rd32_fresh(&ctl[b].helpers);
       if (h >= (u32)room) continue;
