@@ -133,6 +133,19 @@ __device__ __forceinline__ u64 rd64_fresh(u64 *p) { return __hip_atomic_fetch_ad
 __device__ __forceinline__ u32 rd32_fresh(u32 *p) { return __hip_atomic_fetch_add(p, 0u, NDT_RLX, NDT_AGENT); }
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// min / max over the 64 lanes with DPP moves (row shifts, then the rows' results carried along): valid in lane 63
+__device__ __forceinline__ int wave_min_dpp(int x) {
+#define NDT_DPP_MIN(CTRL, ROWS) { const int t_ = __builtin_amdgcn_update_dpp(x, x, CTRL, ROWS, 0xF, false); x = t_ < x ? t_ : x; }
+  NDT_DPP_MIN(0x111, 0xF) NDT_DPP_MIN(0x112, 0xF) NDT_DPP_MIN(0x114, 0xF) NDT_DPP_MIN(0x118, 0xF) NDT_DPP_MIN(0x142, 0xA) NDT_DPP_MIN(0x143, 0xC)
+#undef NDT_DPP_MIN
+  return x;
+}
+__device__ __forceinline__ int wave_max_dpp(int x) {
+#define NDT_DPP_MAX(CTRL, ROWS) { const int t_ = __builtin_amdgcn_update_dpp(x, x, CTRL, ROWS, 0xF, false); x = t_ > x ? t_ : x; }
+  NDT_DPP_MAX(0x111, 0xF) NDT_DPP_MAX(0x112, 0xF) NDT_DPP_MAX(0x114, 0xF) NDT_DPP_MAX(0x118, 0xF) NDT_DPP_MAX(0x142, 0xA) NDT_DPP_MAX(0x143, 0xC)
+#undef NDT_DPP_MAX
+  return x;
+}
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { int t = __shfl_down(v, o); v = t < v ? t : v; }
@@ -609,8 +622,8 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
         mny = iy < mny ? iy : mny; mxy = iy > mxy ? iy : mxy;
       }
     }
-    mnx = wave_min_i(mnx); mny = wave_min_i(mny); mxx = wave_max_i(mxx); mxy = wave_max_i(mxy);
-    if ((threadIdx.x & 63) == 0 && mnx <= mxx) {
+    mnx = wave_min_dpp(mnx); mny = wave_min_dpp(mny); mxx = wave_max_dpp(mxx); mxy = wave_max_dpp(mxy);
+    if ((threadIdx.x & 63) == 63 && mnx <= mxx) {
       atomicMin(&L.sbox[0], mnx); atomicMin(&L.sbox[1], mny); atomicMax(&L.sbox[2], mxx); atomicMax(&L.sbox[3], mxy);
     }
   }
@@ -681,24 +694,28 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
   // no gather from memory, no scattered 8-byte stores (10k of those per workgroup took 13 us to drain).
   {
     const uint4 *idx4 = reinterpret_cast<const uint4 *>(idx);
+    unsigned v[PER]; int s0[PER], s1[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) v[u] = idx[min((int)threadIdx.x + u * kBlock, n - 1)];      // all in flight
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {                                                            // all in flight
+      const int k = (int)(v[u] >> 15);
+      s0[u] = (int)hist[max(k - 1, 0)]; s1[u] = (int)hist[k];
+      if (k == 0) s0[u] = 0;
+      if ((int)threadIdx.x + u * kBlock >= n) s1[u] = s0[u];
+    }
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int pp = (int)threadIdx.x + u * kBlock;
-      if (pp < n) {
-        const unsigned v = idx[pp];
-        const int k = (int)(v >> 15);
-        const int s0 = k ? (int)hist[k - 1] : 0, s1 = (int)hist[k];
-        int rank = 0;
-        for (int q = s0 >> 2; q <= (s1 - 1) >> 2; ++q) {                 // aligned quads covering [s0, s1)
-          const uint4 e = idx4[q];
-          const int a = q << 2;
-          rank += (a >= s0 && a < s1 && e.x < v) ? 1 : 0;
-          rank += (a + 1 >= s0 && a + 1 < s1 && e.y < v) ? 1 : 0;
-          rank += (a + 2 >= s0 && a + 2 < s1 && e.z < v) ? 1 : 0;
-          rank += (a + 3 >= s0 && a + 3 < s1 && e.w < v) ? 1 : 0;
-        }
-        inv[v & 0x7FFFu] = (unsigned)(s0 + rank);
+      int rank = 0;
+      for (int q = s0[u] >> 2; q <= (s1[u] - 1) >> 2 && s1[u] > s0[u]; ++q) {   // aligned quads covering [s0, s1)
+        const uint4 e = idx4[q];
+        const int a = q << 2;
+        rank += (a >= s0[u] && a < s1[u] && e.x < v[u]) ? 1 : 0;
+        rank += (a + 1 >= s0[u] && a + 1 < s1[u] && e.y < v[u]) ? 1 : 0;
+        rank += (a + 2 >= s0[u] && a + 2 < s1[u] && e.z < v[u]) ? 1 : 0;
+        rank += (a + 3 >= s0[u] && a + 3 < s1[u] && e.w < v[u]) ? 1 : 0;
       }
+      if (s1[u] > s0[u]) inv[v[u] & 0x7FFFu] = (unsigned)(s0[u] + rank);
     }
   }
   NDT_STAMP(stamps, t0s, 11);
@@ -1027,8 +1044,10 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         drain_vmem();
         __syncthreads();
         if (threadIdx.x == 0) {
+#ifndef NDT_EXPERIMENT_NO_RELEASE
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
           drain_vmem();
+#endif
           st64(&C->ticket, (u64)1 << 32);                     // epoch 1: open for joining, nothing to compute (h = 0)
         }
       }

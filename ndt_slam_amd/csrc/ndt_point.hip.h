@@ -144,14 +144,27 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
   const int rw3 = R.rw - 3;                    // slot of neighbour k = 3 r + q: srow[r * rw + q] = srow[r * (rw - 3) + k]
   unsigned mask = 0;
   float lowx = INFINITY;                       // -inf <=> one of the nine voxels is occupied but not resident
+  // (the nine slot numbers first, then the nine centroids: left to itself the scheduler waited for the first slot before
+  //  it issued the other eight reads -- a whole LDS round trip exposed per point)
+  unsigned short sl[9];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      const float2 cc = W.ent[srow[r * R.rw + q]].cent;
-      lowx = fminf(lowx, cc.x);
-      mask |= in_radius<INCL>(M.r2, xt, yt, cc) << (r * 3 + q);
-    }
+    for (int q = 0; q < 3; ++q) sl[r * 3 + q] = srow[r * R.rw + q];
+#ifndef NDT_NO_PROBE_SCHED
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  float2 cc[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) cc[k] = W.ent[sl[k]].cent;
+#ifndef NDT_NO_PROBE_SCHED
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    lowx = fminf(lowx, cc[k].x);
+    mask |= in_radius<INCL>(M.r2, xt, yt, cc[k]) << k;
+  }
   const double nd2 = -M.d2, nd2h = nd2 * 0.5;
   if (inwin & (lowx != -INFINITY)) {
     if (!mask) return;
