@@ -227,12 +227,16 @@ map_scatter_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDi
 }
 
 // Restore input order inside every bucket (PCL accumulates a voxel's points in cloud order and
-// its float32 centroid sum depends on that order), rank by counting.  Voxels of up to kBigVoxel
+// its float32 centroid sum depends on that order), rank by counting.  Round 3: the POINT goes to its ranked place (the
+// bucketed copy `pts` the fitness search reads anyway), not its number: the gather by point number -- a million random
+// 8-byte reads -- happens here, spread over every lane of the chip, and map_finalize_kernel streams a voxel's points from
+// consecutive addresses instead of chasing number -> point through two dependent loads per batch (47 -> .. us).  Voxels of up to kBigVoxel
 // points: eight lanes per voxel (one wave per voxel spent its time launching waves, 70 % of the
 // voxels being empty); the others, listed by scan_apply_kernel: one wave per voxel.
 constexpr int kOrderVoxPerBlock = 256 / 8 * 4;     // 32 lane groups, 4 voxels each
 __device__ __forceinline__ void order_small_voxels(unsigned block, const int *__restrict__ start, size_t ng,
-                                                   const int *__restrict__ perm, int *__restrict__ perm_sorted) {
+                                                   const int *__restrict__ perm, const float *__restrict__ xy, size_t stride,
+                                                   float2 *__restrict__ pts) {
   const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
   for (int r = 0; r < 4; ++r) {
     const size_t g = (size_t)block * kOrderVoxPerBlock + (size_t)r * 32 + grp;
@@ -243,7 +247,7 @@ __device__ __forceinline__ void order_small_voxels(unsigned block, const int *__
       const int mine = perm[s0 + e];
       int rank = 0;
       for (int j = 0; j < n; ++j) rank += (perm[s0 + j] < mine) ? 1 : 0;
-      perm_sorted[s0 + rank] = mine;
+      pts[s0 + rank] = load_pt(xy, stride, (size_t)mine);   // the point itself goes to its place: map_finalize_kernel streams them
     }
   }
 }
@@ -253,9 +257,10 @@ constexpr int kBigWavesPerBlock = 4, kBigBlocks = 1024, kBigStage = 512;   // LD
 // the kBigBlocks behind them the listed big ones.
 __global__ void __launch_bounds__(256)
 map_order_kernel(const int *__restrict__ start, size_t ng, unsigned small_blocks, const int *__restrict__ big,
-                 const int *__restrict__ nbig, int big_cap, const int *__restrict__ perm, int *__restrict__ perm_sorted) {
+                 const int *__restrict__ nbig, int big_cap, const int *__restrict__ perm, const float *__restrict__ xy,
+                 size_t stride, float2 *__restrict__ pts) {
   __shared__ int stage[kBigWavesPerBlock][kBigStage];
-  if (blockIdx.x < small_blocks) { order_small_voxels(blockIdx.x, start, ng, perm, perm_sorted); return; }
+  if (blockIdx.x < small_blocks) { order_small_voxels(blockIdx.x, start, ng, perm, xy, stride, pts); return; }
   const unsigned bblock = blockIdx.x - small_blocks, bblocks = gridDim.x - small_blocks;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int count = min(*nbig, big_cap);
@@ -270,7 +275,7 @@ map_order_kernel(const int *__restrict__ start, size_t ng, unsigned small_blocks
       int rank = 0;
       if (staged) { for (int j = 0; j < n; ++j) rank += (stage[wv][j] < mine) ? 1 : 0; }
       else        { for (int j = 0; j < n; ++j) rank += (perm[s0 + j] < mine) ? 1 : 0; }
-      perm_sorted[s0 + rank] = mine;
+      pts[s0 + rank] = load_pt(xy, stride, (size_t)mine);
     }
   }
 }
@@ -355,9 +360,9 @@ __device__ __forceinline__ int write_voxel(const GridDims &G, const LeafParams &
 // One lane per voxel: sequential sums in cloud order (float32 centroid, fp64 mean / Sxx), bucketed
 // copy of the raw points, cell record.
 __global__ void __launch_bounds__(256)
-map_finalize_kernel(const float *__restrict__ xy, size_t stride, GridDims G, LeafParams L,
-                          const int *__restrict__ start, const int *__restrict__ perm_sorted,
-                          float2 *__restrict__ pts, float2 *__restrict__ cent, double *__restrict__ rec,
+map_finalize_kernel(GridDims G, LeafParams L,
+                          const int *__restrict__ start,
+                          const float2 *__restrict__ pts, float2 *__restrict__ cent, double *__restrict__ rec,
                           int *__restrict__ npts_grid, int *__restrict__ counters /* unused */,
                           unsigned *__restrict__ occ /* (ng + 31) / 32 words: voxel in the search set */) {
   const size_t ng = (size_t)G.div_x * G.div_y;
@@ -371,17 +376,14 @@ map_finalize_kernel(const float *__restrict__ xy, size_t stride, GridDims G, Lea
     float fx = 0.f, fy = 0.f;
     double sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0, szz = 0;
     if (L.cov_init_identity) { sxx = 1.0; syy = 1.0; szz = 1.0; }
-    for (int s = s0; s < s1; s += 8) {          // eight gathers in flight
-      int ib[8]; float2 pb[8];
+    for (int s = s0; s < s1; s += 8) {          // eight loads in flight, consecutive addresses (map_order_kernel put the points in cloud order)
+      float2 pb[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) ib[u] = perm_sorted[min(s + u, s1 - 1)];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) pb[u] = load_pt(xy, stride, (size_t)ib[u]);
+      for (int u = 0; u < 8; ++u) pb[u] = pts[min(s + u, s1 - 1)];
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (s + u >= s1) break;
         const float2 p = pb[u];                 // strictly in cloud order: these sums define the voxel
-        pts[s + u] = p;
         fx += p.x; fy += p.y;
         const double X = (double)p.x, Y = (double)p.y;
         sx += X; sy += Y;

@@ -490,7 +490,6 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
     if ((rc = ensure_t(ctx, &m->npts_grid, &m->npts_cap, ng + 1))) return rc;
     if ((rc = ensure_t(ctx, &m->tile, &m->tile_cap, ntiles_ + 1))) return rc;
     if ((rc = ensure_t(ctx, &m->perm, &m->perm_cap, n))) return rc;
-    if ((rc = ensure_t(ctx, &m->perm_sorted, &m->perm_sorted_cap, n))) return rc;
     if ((rc = ensure_t(ctx, &m->big, &m->big_cap, n / kBigVoxel + 1))) return rc;   // voxels with > kBigVoxel points
     if ((rc = ensure_t(ctx, &m->occ, &m->occ_cap, (ng + 31) / 32 + 2))) return rc;
     if ((rc = ensure_t(ctx, &m->pts, &m->pts_cap, n))) return rc;
@@ -528,14 +527,14 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   HIP_TRY(ctx, hipGetLastError());
   m->count_clean = true;
   const unsigned small_blocks = (unsigned)((ng + kOrderVoxPerBlock - 1) / kOrderVoxPerBlock);
-  map_order_kernel<<<small_blocks + kBigBlocks, 256, 0, st>>>(start, ng, small_blocks, m->big, m->counters + 2, big_cap, m->perm, m->perm_sorted);
+  map_order_kernel<<<small_blocks + kBigBlocks, 256, 0, st>>>(start, ng, small_blocks, m->big, m->counters + 2, big_cap, m->perm, xy, stride, m->pts);
   HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_join, 0));
 
   // 4. per-voxel statistics -> centroid grid + cell records + bucketed raw points
   LeafParams L;
   L.min_pts = prm->min_pts; L.cov_unbiased = prm->cov_unbiased; L.cov_init_identity = prm->cov_init_identity;
   L.eig_mult = prm->eig_mult;
-  map_finalize_kernel<<<(unsigned)((ng + 255) / 256), 256, 0, st>>>(xy, stride, G, L, start, m->perm_sorted,
+  map_finalize_kernel<<<(unsigned)((ng + 255) / 256), 256, 0, st>>>(G, L, start,
                                                                           m->pts, m->cent, m->rec, m->npts_grid,
                                                                           m->counters, m->occ);
   HIP_TRY(ctx, hipGetLastError());
