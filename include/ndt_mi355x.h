@@ -182,6 +182,19 @@ int ndt_align_batch(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_host
 int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_dev,
                         const uint64_t *offsets_dev, int B, size_t total_points, int shared_scan,
                         const double *inits_dev, ndt_result *out_dev, void *stream);
+
+/* Many matches over several GPUs from ONE process (north_star: "batch across the 8 GPUs of one node"; SURVEY.md 8b's
+ * indicative multi-device context): `ctxs[r]` / `maps[r]` are a context of device r and a map built there from the same
+ * cloud.  The batch is cut into n_shards contiguous, balanced shards (matches [r B / n, (r + 1) B / n), the first B % n
+ * one longer -- the partition of ndt_slam_amd/shard.py), every shard is uploaded straight to its device, all launches
+ * run side by side, the records come back into results[0 .. B) in batch order.  No exchange between devices: the
+ * matches are independent given the read-only map, so a batch that starts on the host needs no xGMI
+ * traffic at all.  `shared_scan`: the one scan goes to every device, the B seed poses are sharded.  Synchronous; same
+ * results as ndt_align_batch on one device, byte for byte.  (One process per GPU over torch.distributed / RCCL is the
+ * other form: ndt_slam_amd/shard.py.)  Replaces a loop of src/ScanMatcher.cpp:40,45 over independent scans. */
+int ndt_align_batch_sharded(ndt_ctx *const *ctxs, const ndt_map *const *maps, int n_shards, const float *scans_xy_host,
+                            const uint64_t *offsets, int B, int shared_scan, const double *inits_xyyaw,
+                            ndt_result *results);
 /* As ndt_align_batch, additionally recording per derivative pass of every match
  * 8 doubles {a_t, score, g0, g1, g2, p0, p1, p2} (parity tests: same step sequence as the
  * oracle).  trace_host: B x trace_cap x 8 doubles; trace_rows_host: B ints. */

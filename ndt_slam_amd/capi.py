@@ -57,7 +57,7 @@ EXPORTS = [
     "ndt_ctx_set_stream", "ndt_ctx_set_option", "ndt_ctx_wait_launch",
     "ndt_map_build", "ndt_map_build_dev", "ndt_map_rebuild_begin", "ndt_map_rebuild_end", "ndt_map_destroy", "ndt_map_info_get", "ndt_map_export",
     "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_trace", "ndt_eval_at",
-    "ndt_fitness_at", "ndt_last_timing", "ndt_kernel_timing", "ndt_launch_interval", "ndt_prefilter", "ndt_prefilter_batch_dev",
+    "ndt_fitness_at", "ndt_last_timing", "ndt_kernel_timing", "ndt_launch_interval", "ndt_align_batch_sharded", "ndt_prefilter", "ndt_prefilter_batch_dev",
     "ndt_fuse_default_params", "ndt_predict_batch_dev", "ndt_fuse_batch_dev",
     "ndt_remove_neighbors", "ndt_remove_neighbors_dev",
     "ndt_difference_extraction", "ndt_difference_extraction_dev", "ndt_make_map", "ndt_make_map_dev",
@@ -101,6 +101,7 @@ def lib():
     L.ndt_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ndt_kernel_timing.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ndt_launch_interval.argtypes = [vp, i, C.POINTER(C.c_float)]
+    L.ndt_align_batch_sharded.argtypes = [vp, vp, i, vp, vp, i, i, vp, vp]
     L.ndt_prefilter.argtypes = [vp, vp, sz, sz, C.c_float, vp, C.POINTER(sz)]
     L.ndt_prefilter_batch_dev.argtypes = [vp, vp, sz, vp, i, sz, C.c_float, vp, vp, vp]
     L.ndt_fuse_default_params.argtypes = [C.POINTER(FuseParams)]
@@ -133,6 +134,23 @@ def default_params(preset="default", **kw):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+def align_batch_sharded(maps, scans, offsets, inits, shared_scan=False):
+    """ndt_align_batch_sharded: `maps` = one Map per device (each with its own Context), the batch on the host."""
+    scans = _f32c(scans)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    inits = np.ascontiguousarray(inits, dtype=np.float64).reshape(-1, 3)
+    B = len(inits)
+    res = np.zeros(B, dtype=RESULT_DTYPE)
+    n = len(maps)
+    cx = (C.c_void_p * n)(*[m.ctx.h for m in maps])
+    mp = (C.c_void_p * n)(*[m.h for m in maps])
+    rc = lib().ndt_align_batch_sharded(cx, mp, n, scans.ctypes.data, offsets.ctypes.data, B, int(shared_scan),
+                                       inits.ctypes.data, res.ctypes.data)
+    if rc:
+        raise NdtError("ndt_align_batch_sharded -> %d: %s" % (rc, lib().ndt_last_error(None).decode()))
+    return res
 
 
 def default_fuse_params(**kw):

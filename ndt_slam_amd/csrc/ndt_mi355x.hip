@@ -806,8 +806,8 @@ void prof_report(const unsigned long long *hp, int B) {
 
 // Host-pointer matches: stage scans (records of `stride` bytes, repacked to float2 on the device when stride != 8),
 // offsets and initial guesses, run the batch, copy the records back; synchronous.
-int align_host(ndt_ctx *ctx, const ndt_map *map, const float *scans, size_t stride, const uint64_t *offsets, int B,
-               int shared_scan, const double *inits, ndt_result *out, double *trace, int trace_cap, int *trace_rows) {
+int align_host_queue(ndt_ctx *ctx, const ndt_map *map, const float *scans, size_t stride, const uint64_t *offsets, int B,
+                     int shared_scan, const double *inits, ndt_result *out, double *trace, int trace_cap, int *trace_rows) {
   if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
   if (!map || !scans || !offsets || !inits || !out || B <= 0 || stride < 8 || (stride & 3))
     return fail(ctx, NDT_E_ARG, "ndt_align_batch: bad arguments");
@@ -869,10 +869,20 @@ int align_host(ndt_ctx *ctx, const ndt_map *map, const float *scans, size_t stri
     HIP_TRY(ctx, hipMemcpyAsync(trace, d_trace, (size_t)B * trace_cap * 64, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(trace_rows, d_rows, (size_t)B * 4, hipMemcpyDeviceToHost, st));
   }
-  if ((rc = scratch_end(ctx, st))) return rc;
-  HIP_TRY(ctx, hipStreamSynchronize(st));
+  return scratch_end(ctx, st);
+}
+
+int align_host_finish(ndt_ctx *ctx) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
   HIP_TRY(ctx, hipEventElapsedTime(&ctx->align_ms, ctx->ev0, ctx->ev1));
   return NDT_OK;
+}
+
+int align_host(ndt_ctx *ctx, const ndt_map *map, const float *scans, size_t stride, const uint64_t *offsets, int B,
+               int shared_scan, const double *inits, ndt_result *out, double *trace, int trace_cap, int *trace_rows) {
+  const int rc = align_host_queue(ctx, map, scans, stride, offsets, B, shared_scan, inits, out, trace, trace_cap, trace_rows);
+  return rc ? rc : align_host_finish(ctx);
 }
 
 }  // namespace
@@ -888,6 +898,39 @@ int ndt_align_batch_trace(ndt_ctx *ctx, const ndt_map *map, const float *scans, 
 int ndt_align_batch(ndt_ctx *ctx, const ndt_map *map, const float *scans, const uint64_t *offsets, int B,
                     int shared_scan, const double *inits, ndt_result *out) {
   return align_host(ctx, map, scans, 8, offsets, B, shared_scan, inits, out, nullptr, 0, nullptr);
+}
+
+int ndt_align_batch_sharded(ndt_ctx *const *ctxs, const ndt_map *const *maps, int n_shards, const float *scans,
+                            const uint64_t *offsets, int B, int shared_scan, const double *inits, ndt_result *out) {
+  if (!ctxs || !maps || n_shards <= 0 || !scans || !offsets || !inits || !out || B <= 0)
+    return fail(nullptr, NDT_E_ARG, "ndt_align_batch_sharded: bad arguments");
+  for (int r = 0; r < n_shards; ++r)
+    if (!ctxs[r] || !maps[r]) return fail(nullptr, NDT_E_ARG, "ndt_align_batch_sharded: null context or map");
+  // contiguous, balanced shards: the first B % n_shards get one match more (ndt_slam_amd/shard.py: shard_bounds)
+  const int base = B / n_shards, extra = B % n_shards;
+  std::vector<std::vector<uint64_t>> offs((size_t)n_shards);
+  std::vector<int> queued((size_t)n_shards, 0);
+  int rc_first = NDT_OK;
+  for (int r = 0; r < n_shards; ++r) {            // queue every shard on its own device: uploads, launch, read-back
+    const int lo = r * base + std::min(r, extra), n = base + (r < extra ? 1 : 0);
+    if (n == 0) continue;
+    int rc;
+    if (shared_scan) {
+      rc = align_host_queue(ctxs[r], maps[r], scans, 8, offsets, n, 1, inits + 3 * (size_t)lo, out + lo, nullptr, 0, nullptr);
+    } else {
+      offs[r].resize((size_t)n + 1);
+      for (int k = 0; k <= n; ++k) offs[r][k] = offsets[lo + k] - offsets[lo];
+      rc = align_host_queue(ctxs[r], maps[r], scans + 2 * (size_t)offsets[lo], 8, offs[r].data(), n, 0, inits + 3 * (size_t)lo,
+                            out + lo, nullptr, 0, nullptr);
+    }
+    if (rc) { if (!rc_first) rc_first = rc; } else queued[r] = 1;
+  }
+  for (int r = 0; r < n_shards; ++r) {            // ... then wait for all of them
+    if (!queued[r]) continue;
+    const int rc = align_host_finish(ctxs[r]);
+    if (rc && !rc_first) rc_first = rc;
+  }
+  return rc_first;
 }
 
 int ndt_align(ndt_ctx *ctx, const ndt_map *map, const float *scan, size_t n, size_t stride,

@@ -441,6 +441,36 @@ def test_multi_hypothesis_shared_scan(gpu, oracle, c1_world):
     assert best == int(np.argmax(ref_all))
 
 
+def test_sharded_batch_from_one_process(gpu, c1_world):
+    """ndt_align_batch_sharded: one process, one context + map per device (here: several contexts of device 0 -- the box has
+    one GPU), the batch cut into contiguous balanced shards, records back in batch order: byte-identical to one launch on
+    one context.  7 ragged scans over 3 shards, over 8 shards (the last one empty), and 5 seed poses of one scan over 2."""
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    prm = capi.default_params(resolution=cfg["resolution"])
+    scans, off, truths, inits = sf.batch(0, 7)
+    keep = np.ones(len(scans), bool); keep[int(off[2]):int(off[2]) + 17] = False
+    lens = np.diff(off.astype(np.int64)); lens[2] -= 17
+    scans = scans[keep]; off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    one = capi.Map(ctx, m, prm).align_batch(scans, off, inits)
+    ctxs = [capi.Context(0) for _ in range(8)]
+    maps = [capi.Map(c, m, prm) for c in ctxs]
+    for n in (1, 3, 8):
+        got = capi.align_batch_sharded(maps[:n], scans, off, inits)
+        assert got.tobytes() == one.tobytes(), "%d shards" % n
+    scan0 = scans[:int(off[1])]
+    seeds = inits[0] + np.array([[0, 0, 0], [0.1, 0, 0], [0, -0.1, 0.01], [0.05, 0.05, -0.01], [-0.1, 0.02, 0]])
+    one_s = maps[0].align_batch(scan0, off[:2], seeds, shared_scan=True)
+    got_s = capi.align_batch_sharded(maps[:2], scan0, off[:2], seeds, shared_scan=True)
+    assert got_s.tobytes() == one_s.tobytes()
+    with pytest.raises(capi.NdtError):
+        capi.align_batch_sharded(maps[:2], scans, off, inits[:0])
+    for mp in maps:
+        mp.close()
+    for c in ctxs:
+        c.close()
+
+
 def test_pointxyz_records_equal_packed_points(gpu, c1_world):
     """`pcl::PointXYZ` records (16 bytes: x, y, z, pad -- what the reference's clouds hold) go in as they are
     (stride_bytes = 16, packed on the device): map, match and fitness equal the packed float2 path byte for byte."""
