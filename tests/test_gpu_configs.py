@@ -150,7 +150,8 @@ def test_hbm_fallback_paths_match_oracle(gpu, oracle, world_5m):
 
 def test_scan_above_the_lds_sort_limit(gpu, oracle, world_1m):
     """Scans above 20000 points are not re-ordered (NDT_FLAG_UNSORTED) and above the staging limits read from HBM;
-    30k and 70k points against the oracle."""
+    30k and 70k points against the oracle.  Scans of 10241 .. 20000 points are ordered by the streaming routines
+    (compute_region + sort_points) instead of the register-resident set-up of the 10k-point scans: 15k points."""
     capi, ctx = gpu
     from ndt_slam_amd import synth
     m, _, cfg = world_1m
@@ -162,3 +163,16 @@ def test_scan_above_the_lds_sort_limit(gpu, oracle, world_1m):
         r = gm.align(scan, init)
         assert int(r["flags"]) & capi.FLAG_UNSORTED
         assert_result_parity(r, om.align(scan, init))
+    sf = synth.ScanFactory(m, cfg["half"], 15_000, radius=35.0)
+    for k in (1, 2):
+        scan, truth, init = sf.make(k)
+        r = gm.align(scan, init)
+        assert not (int(r["flags"]) & capi.FLAG_UNSORTED)
+        assert_result_parity(r, om.align(scan, init))
+    # a mixed batch: both set-up routines and the unordered path side by side in one launch
+    parts = [synth.ScanFactory(m, cfg["half"], n, radius=40.0).make(5)[:3:2] for n in (9_000, 15_000, 10_240, 10_241, 25_000)]
+    scans = np.concatenate([p[0] for p in parts]); inits = np.stack([p[1] for p in parts])
+    off = np.concatenate([[0], np.cumsum([len(p[0]) for p in parts])]).astype(np.uint64)
+    res = gm.align_batch(scans, off, inits)
+    for b in range(len(parts)):
+        assert_result_parity(res[b], om.align(parts[b][0], parts[b][1]))
