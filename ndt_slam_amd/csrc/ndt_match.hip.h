@@ -132,6 +132,16 @@ __device__ __forceinline__ void st32(u32 *p, u32 v) { __hip_atomic_store(p, v, N
 __device__ __forceinline__ u64 rd64_fresh(u64 *p) { return __hip_atomic_fetch_add(p, 0ull, NDT_RLX, NDT_AGENT); }
 __device__ __forceinline__ u32 rd32_fresh(u32 *p) { return __hip_atomic_fetch_add(p, 0u, NDT_RLX, NDT_AGENT); }
 __device__ __forceinline__ void drain_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// 16- / 8-byte stores that write through to memory (sc1: what an agent-scope atomic store is on gfx942 / gfx950), for bulk
+// data another XCD will read: once they are drained no agent-scope release -- a write-back of the XCD's whole L2 -- is needed
+__device__ __forceinline__ void st_wt_f4(float4 *p, float4 v) {
+  const ndt_f4v x = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void st_wt_f2(float2 *p, float2 v) {
+  const ndt_f2v x = {v.x, v.y};
+  asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+}
 
 // min / max over the 64 lanes with DPP moves (row shifts, then the rows' results carried along): valid in lane 63
 __device__ __forceinline__ int wave_min_dpp(int x) {
@@ -734,11 +744,12 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
     const float4 *st4 = reinterpret_cast<const float4 *>(pool);
     float4 *sp4 = reinterpret_cast<float4 *>(sp);                      // (scratch slots start at even point numbers? see below)
     const bool aligned = (reinterpret_cast<size_t>(sp) & 15) == 0;
+    // write-through: helpers on other XCDs read this copy (see the publishing step in the kernel)
     if (aligned) {
-      for (int i = threadIdx.x; i < n / 2; i += kBlock) sp4[i] = st4[i];
-      if (threadIdx.x == 0 && (n & 1)) sp[n - 1] = stage[n - 1];
+      for (int i = threadIdx.x; i < n / 2; i += kBlock) st_wt_f4(sp4 + i, st4[i]);
+      if (threadIdx.x == 0 && (n & 1)) st_wt_f2(sp + (n - 1), stage[n - 1]);
     } else {
-      for (int i = threadIdx.x; i < n; i += kBlock) sp[i] = stage[i];
+      for (int i = threadIdx.x; i < n; i += kBlock) st_wt_f2(sp + i, stage[i]);
     }
   }
   __syncthreads();
@@ -1030,24 +1041,27 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
         const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
         unsigned *gw = wantmap + (size_t)b * (kRegionCells / 32);
-        for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) gw[i] = wmap[i];
+        for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) st32(&gw[i], wmap[i]);
       }
       if (allow_helpers) {
         // publish geometry + marked cells + ordered copy before staging the own window, so that idle
-        // workgroups stage theirs meanwhile: plain stores, drained by every wave, then one agent release
+        // workgroups stage theirs meanwhile.  Everything a helper will read is stored write-through (geometry and
+        // marked cells here, the ordered copy in order_scan_regs) and drained by every wave, so the scan is opened
+        // without an agent-scope release -- a write-back of this XCD's whole L2, 3-4 us on the critical path of every
+        // scan.  Scans ordered by the streaming routines (plain stores) keep the release.
         if (threadIdx.x == 0) {
           const Region r = L.RG;
-          C->region[0] = r.x0; C->region[1] = r.y0; C->region[2] = r.rw; C->region[3] = r.rh;
-          C->region[4] = r.cap; C->region[5] = r.nspill;
-          C->use_sorted = (pts != scan) ? 1u : 0u;
+          st32((u32 *)&C->region[0], (u32)r.x0); st32((u32 *)&C->region[1], (u32)r.y0); st32((u32 *)&C->region[2], (u32)r.rw);
+          st32((u32 *)&C->region[3], (u32)r.rh); st32((u32 *)&C->region[4], (u32)r.cap); st32((u32 *)&C->region[5], (u32)r.nspill);
+          st32(&C->use_sorted, (pts != scan) ? 1u : 0u);
         }
         drain_vmem();
         __syncthreads();
         if (threadIdx.x == 0) {
-#ifndef NDT_EXPERIMENT_NO_RELEASE
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          drain_vmem();
-#endif
+          if (!reg_path) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            drain_vmem();
+          }
           st64(&C->ticket, (u64)1 << 32);                     // epoch 1: open for joining, nothing to compute (h = 0)
         }
       }
