@@ -1185,9 +1185,21 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       static_assert(kSub * 12 <= 64 && kUnits == 16 * kSub, "one lane per (group, value)");
       static_assert(sizeof(L.wpart) >= 4096, "the set-up phases keep 4 KiB of bitmaps in L.wpart");
       if (threadIdx.x < 64) {
-        const int j = lane % 12, grp = lane / 12;             // lanes kSub*12..63: nothing to add
+        // (behind every pass with the whole workgroup waiting: the sixteen unit totals of a lane are read in one go -- the
+        //  compiler had paired every read with a wait -- and the lane's place is worked out here each time: kept across
+        //  the pass loop it lived in scratch memory, one reload at memory latency per pass)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int grp = (ln * 43) >> 9, j = ln - 12 * grp;    // lane / 12, lane % 12 for lanes 0..63; lanes kSub*12..63: nothing to add
         double part = 0.0;
-        if (lane < kSub * 12) for (int v = 16 * grp; v < 16 * grp + 16; ++v) part += L.wpart[v * 12 + j];
+        if (ln < kSub * 12) {
+          double uv[16];
+#pragma unroll
+          for (int v = 0; v < 16; ++v) uv[v] = L.wpart[(16 * grp + v) * 12 + j];
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int v = 0; v < 16; ++v) part += uv[v];
+        }
         double total = part;
 #pragma unroll
         for (int g = 1; g < kSub; ++g) total += __shfl(part, j + 12 * g);
