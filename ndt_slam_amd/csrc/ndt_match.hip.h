@@ -889,7 +889,15 @@ __device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_i
   pp.cj = uniform_d(pp_in.cj); pp.sj = uniform_d(pp_in.sj); pp.ch = uniform_d(pp_in.ch); pp.sh = uniform_d(pp_in.sh);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, last = n - 1;
   const int per_lane = (n + kBlock - 1) / kBlock;          // points of the longest lane
-  const int run = (per_lane + kSub - 1) / kSub;
+#ifdef NDT_RUNS_CEIL
+  const int run = (per_lane + kSub - 1) / kSub;              // runs of equal length, the last one short (10 rounds: 3 3 3 1)
+  auto kstart = [&](int q) { return min(per_lane, q * run); };
+#else
+  // runs as equal as they get (10 rounds: 3 3 2 2): in a pass shared by two workgroups every wave then walks a long and
+  // a short unit -- five rounds -- instead of half the waves two long ones (round 3)
+  const int rbase = per_lane / kSub, rextra = per_lane % kSub;
+  auto kstart = [&](int q) { return q * rbase + min(q, rextra); };
+#endif
   for (int it = 0; it <= kUnits; ++it) {                   // counted (tools/repro/ticket2.hip)
     int w, q0, q1, dst_stride;
     double *dst;
@@ -905,11 +913,11 @@ __device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_i
       w = u % kWaves; q0 = u / kWaves; q1 = q0 + 1; dst_stride = 0;
       dst = vtot ? L.wtmp + wave * 12 : L.wpart + u * 12;
     }
-    const int kbeg = min(per_lane, q0 * run), kend = min(per_lane, q1 * run);
+    const int kbeg = kstart(q0), kend = kstart(q1);
     const int base = w * 64 + lane;
     Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
     float2 p0 = gld_f2(pts + min(base + kbeg * kBlock, last)), p1 = gld_f2(pts + min(base + (kbeg + 1) * kBlock, last));
-    int q = q0, kb = min(per_lane, (q0 + 1) * run);        // end of the current run
+    int q = q0, kb = kstart(q0 + 1);                       // end of the current run
 #pragma nounroll
     for (int k = kbeg; k < kend; ++k) {
       const float2 p2 = gld_f2(pts + min(base + (k + 2) * kBlock, last));
@@ -920,7 +928,7 @@ __device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_i
         const double a[12] = {A.e, A.g0, A.g1, A.g2, A.hxx, A.hxy, A.hxt, A.hyy, A.hyt, A.htt, (double)A.pairs, 0.0};
         wave_reduce12(a, lane, dst + (q - q0) * dst_stride);
         A = Acc{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
-        ++q; kb = min(per_lane, (q + 1) * run);
+        ++q; kb = kstart(q + 1);
       }
     }
     for (; q < q1; ++q) {                                  // empty runs (short scans)
