@@ -40,14 +40,16 @@ def world_5m():
 STALE = [0, 1]
 
 
+@pytest.mark.parametrize("preset", ["default", "pcl18", "pcl_new"])
 @pytest.mark.parametrize("stale", STALE)
-def test_c3_full_batch_every_scan_vs_oracle(gpu, oracle, world_1m, stale):
-    """configs[2]: all 256 scans of the bench batch against the oracle, under both settings of stale_h_ang."""
+def test_c3_full_batch_every_scan_vs_oracle(gpu, oracle, world_1m, stale, preset):
+    """configs[2]: all 256 scans of the bench batch against the oracle, under both settings of stale_h_ang and under
+    every PCL-version preset (the presets change the voxel statistics and the float32 transform, i.e. every pass)."""
     capi, ctx = gpu
     m, sf, cfg = world_1m
     scans, off, truths, inits = sf.batch(0, 256)
-    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"], stale_h_ang=stale))
-    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"], stale_h_ang=stale))
+    gm = capi.Map(ctx, m, capi.default_params(preset, resolution=cfg["resolution"], stale_h_ang=stale))
+    om = oracle.Map(m, oracle.default_params(preset, resolution=cfg["resolution"], stale_h_ang=stale))
     res = gm.align_batch(scans, off, inits)
     ref = om.align_batch(scans, off, inits, nthreads=NTHREADS)
     for b in range(256):
