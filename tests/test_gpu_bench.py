@@ -81,3 +81,20 @@ def test_bench_c5_and_two_launches_in_flight():
         d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
         assert d["parity"]["max_dpos_m"] <= 1e-4 and d["parity"]["max_dyaw_rad"] <= 1e-4 and d["parity"]["same_iters"]
         assert 0 < d["roofline"]["frac"] < 1 and d["value"] > 0
+
+
+def test_four_rank_path_with_the_ranks_contending_for_one_gpu():
+    """Four ranks over gloo on the ONE device of the box: the scatter / gather bookkeeping at world size 4, and four
+    processes whose persistent match kernels compete for the same CUs -- no launch has all its workgroups resident, so
+    this only finishes in time because workgroups take over the scans of workgroups that are not running (claims)."""
+    env = dict(os.environ, NDT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+                          "--master-addr", "127.0.0.1", "--master-port", "29523", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "4", "--steps", "4", "--warmup", "2", "--no-single-scan", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 4 and d["value"] > 0 and len(d["per_rank"]["kernel_ms"]) == 4
+    assert "scatter_error" not in d["comm"] and "gather_error" not in d["comm"]
+    assert max(d["per_rank"]["kernel_ms_max"]) < 50.0              # ms: no launch waited for another process's kernels to end
+    assert d["converged"] == 256 and d["accepted"] == 256
