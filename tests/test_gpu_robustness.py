@@ -35,7 +35,8 @@ def hog(tmp_path_factory):
     return L
 
 
-def test_match_launches_beside_foreign_queues(hog):
+@pytest.mark.parametrize("B", [256, 24])
+def test_match_launches_beside_foreign_queues(hog, B):
     import torch
     from ndt_slam_amd import capi, synth
     dev = torch.device("cuda", 0)
@@ -49,7 +50,6 @@ def test_match_launches_beside_foreign_queues(hog):
     cfg = synth.CONFIGS["C3"]
     m = synth.make_map(cfg["n_map"], cfg["half"])
     sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
-    B = 256
     scans, off, truths, inits = sf.batch(0, B)
     ctx = capi.Context(0)
     st = torch.cuda.Stream(device=dev)
@@ -93,6 +93,7 @@ def test_match_launches_beside_foreign_queues(hog):
         assert r.tobytes() == first.tobytes(), "records changed beside the foreign kernel (round %d)" % rnd
     torch.cuda.synchronize()
     a, q, h = float(np.median(t_alone)), float(np.median(t_quiet)), float(np.median(t_hog))
+    print("B=%d " % B, end="")
     print("match + fitness per launch: alone %.3f ms, with idle / low-priority streams %.3f ms, beside a 48-CU foreign kernel "
           "median %.3f ms max %.3f ms (%d launches, slowdown %.2fx)" % (a, q, h, max(t_hog), len(t_hog), h / a))
     assert max(t_hog) < 50.0 and max(t_quiet) < 50.0
