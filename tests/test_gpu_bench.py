@@ -98,3 +98,40 @@ def test_four_rank_path_with_the_ranks_contending_for_one_gpu():
     assert "scatter_error" not in d["comm"] and "gather_error" not in d["comm"]
     assert max(d["per_rank"]["kernel_ms_max"]) < 50.0              # ms: no launch waited for another process's kernels to end
     assert d["converged"] == 256 and d["accepted"] == 256
+
+
+_RCCL_ONE = r"""
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from ndt_slam_amd import shard
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%r, RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)                  # "nccl" IS RCCL on ROCm
+rng = np.random.default_rng(1)
+off = np.array([0, 5, 5, 12], np.uint64); scans = rng.standard_normal((12, 2)).astype(np.float32); inits = rng.standard_normal((3, 3))
+sc, of, ini = shard.scatter_batch(scans, off, inits, src=0, device=dev)
+assert sc.is_cuda and sc.cpu().numpy().tobytes() == scans.tobytes() and of.cpu().tolist() == [0, 5, 5, 12]
+pay = torch.arange(2003, dtype=torch.float64, device=dev); dist.broadcast(pay, src=0)
+got = shard.gather_results(torch.arange(216, dtype=torch.uint8, device=dev), dst=0)
+assert len(got) == 1 and got[0].cpu().tolist() == list(range(216))
+t, i = shard.best_hypothesis_t(torch.tensor([0.5, 2.5, 2.5], dtype=torch.float64, device=dev), torch.tensor([8, 16, 24], dtype=torch.int64, device=dev))
+assert float(t) == 2.5 and int(i) == 16
+m = torch.tensor([1.25], dtype=torch.float64, device=dev); dist.all_reduce(m, op=dist.ReduceOp.MAX)
+lst = [torch.empty(3, dtype=torch.float64, device=dev)]; dist.all_gather(lst, torch.tensor([1.0, 2.0, 3.0], dtype=torch.float64, device=dev))
+dist.barrier(); torch.cuda.synchronize()
+dist.destroy_process_group()
+print("RCCL_OK")
+"""
+
+
+def test_the_collectives_of_the_sharded_path_execute_on_rccl():
+    """Every collective bench.py and shard.py issue at N > 1 (object broadcast, float64 broadcast, uint8 gather, float64 MAX /
+    int64 MIN all-reduce, all-gather, barrier), issued once on the real backend -- RCCL -- with device tensors, in a world of
+    one (the box has one GPU and RCCL refuses two ranks on a device): the library loads, the communicator comes up under this
+    image's IPC settings, and the dtypes / reduce ops are ones RCCL implements.  Point-to-point transfers need a peer and stay
+    covered by gloo (tests/test_shard_gloo.py, test_shard_units.py)."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = str(s.getsockname()[1]); s.close()
+    out = subprocess.run([sys.executable, "-c", _RCCL_ONE % (ROOT, port)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
