@@ -18,6 +18,8 @@ struct MapView {
   const double *rec;                 // gw*gh records of 8 doubles (64 B):
                                      // mean_x, mean_y, icov_xx, icov_xy, icov_yy, 3 pad
   const unsigned *occ;               // one bit per voxel of the unpadded grid: in the centroid search set
+  const unsigned long long *tiles;   // which voxels hold raw points, 8 x 8 voxels per word (bit 8 (y & 7) + (x & 7)), tile
+  int tiles_w;                       // (tx, ty) at [(ty + 1) tiles_w + tx + 1]: one tile of zeros all around (a7, far queries)
   const int *pt_start;               // div_x*div_y + 1 bucket offsets of the raw points
   const float2 *pts;                 // raw points bucketed by voxel, input order kept (a7)
   double d1, d2;                     // Gaussian constants (a3)
@@ -92,6 +94,7 @@ __device__ __forceinline__ double2 gld_d2(const double *p) {
 }
 __device__ __forceinline__ double gld_d(const double *p) { return *(const NDT_GLOBAL double *)p; }
 __device__ __forceinline__ int gld_i(const int *p) { return *(const NDT_GLOBAL int *)p; }
+__device__ __forceinline__ unsigned long long gld_u64(const unsigned long long *p) { return *(const NDT_GLOBAL unsigned long long *)p; }
 
 __device__ __forceinline__ float2 load_pt(const float *xy, size_t stride, size_t i) {
   return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(xy) + i * stride);

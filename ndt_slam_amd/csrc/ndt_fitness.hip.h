@@ -81,6 +81,18 @@ struct NearState {
   int rs[4], rn[4];               // ring 1 as (up to) four ranges of the bucketed points: start, length
 };
 
+// distances from the query to the four walls of its voxel, shrunk by 1e-3 leaf so that a point
+// the float32 voxel rounding put on the other side of a wall is never pruned away
+// (the cell of a stored point comes from floorf(x * inv_leaf) in float32: the point can sit |x| 2^-23 beyond the wall)
+__device__ __forceinline__ void near_walls(const MapView &M, float qx, float qy, int cx, int cy, bool inside, NearState &S) {
+  const float L = M.leaf, slack = fmaxf(1e-3f * L, 2.5e-7f * (fabsf(qx) + fabsf(qy) + L));
+  const float fx = qx - (float)(cx + M.min_bx) * L, fy = qy - (float)(cy + M.min_by) * L;
+  float wl = fmaxf(fx - slack, 0.f), wr = fmaxf(L - fx - slack, 0.f);
+  float wd = fmaxf(fy - slack, 0.f), wu = fmaxf(L - fy - slack, 0.f);
+  if (!inside) { wl = wr = wd = wu = 0.f; }            // clamped query: no pruning
+  S.wl = wl; S.wr = wr; S.wd = wd; S.wu = wu;
+}
+
 // Phase 1: the home voxel, then which ring-1 voxels can still matter -- left / right voxel of the home row and the rows
 // below and above as one range each, every voxel pruned by its box distance against the home voxel's best.
 // (Pruning against `best` as it was after the home voxel scans a few more points than pruning range by range; the
@@ -91,15 +103,8 @@ __device__ __forceinline__ NearState nearest_home(const MapView &M, float qx, fl
   S.cx = cx; S.cy = cy;
   const I4u h = P.h;
   float best = scan_bucket(M.pts, h.y, h.z, qx, qy, INFINITY);
-  // distances from the query to the four walls of its voxel, shrunk by 1e-3 leaf so that a point
-  // the float32 voxel rounding put on the other side of a wall is never pruned away
-  // (the cell of a stored point comes from floorf(x * inv_leaf) in float32: the point can sit |x| 2^-23 beyond the wall)
-  const float L = M.leaf, slack = fmaxf(1e-3f * L, 2.5e-7f * (fabsf(qx) + fabsf(qy) + L));
-  const float fx = qx - (float)(cx + M.min_bx) * L, fy = qy - (float)(cy + M.min_by) * L;
-  float wl = fmaxf(fx - slack, 0.f), wr = fmaxf(L - fx - slack, 0.f);
-  float wd = fmaxf(fy - slack, 0.f), wu = fmaxf(L - fy - slack, 0.f);
-  if (!P.inside) { wl = wr = wd = wu = 0.f; }          // clamped query: no pruning
-  S.wl = wl; S.wr = wr; S.wd = wd; S.wu = wu;
+  near_walls(M, qx, qy, cx, cy, P.inside, S);
+  const float wl = S.wl, wr = S.wr, wd = S.wd, wu = S.wu;
   S.best = best;
   const float wmin = fminf(fminf(wl, wr), fminf(wd, wu));
   S.more = wmin * wmin < best;                         // else: no other voxel can hold a closer point
@@ -214,7 +219,7 @@ __device__ __forceinline__ float nearest_ring1_wave(const MapView &M, RingLds &R
 
 // Phase 3: whole rings while the best distance exceeds the ring bound (rare: a query farther than a voxel from every
 // map point of its 3 x 3 neighbourhood).
-__device__ __forceinline__ float nearest_far(const MapView &M, float qx, float qy, const NearState &S, float best) {
+__device__ __forceinline__ float nearest_far(const MapView &M, float qx, float qy, const NearState &S, float best, int r0 = 1) {
   if (!S.more) return best;
   const int cx = S.cx, cy = S.cy;
   const float wl = S.wl, wr = S.wr, wd = S.wd, wu = S.wu, L = M.leaf;
@@ -222,7 +227,7 @@ __device__ __forceinline__ float nearest_far(const MapView &M, float qx, float q
   const int *__restrict__ ps = M.pt_start;
   const double Ld = (double)L;
   const int rmax = M.div_x > M.div_y ? M.div_x : M.div_y;
-  for (int r = 1; r <= rmax; ++r) {
+  for (int r = r0; r <= rmax; ++r) {                    // (r0: everything within r0 voxels has been seen already)
     const double bound = (double)r * Ld * 0.999;        // unvisited points are farther than r*L
     if ((double)best <= bound * bound) break;
     const int R = r + 1;                                // ring R, pruned by box distances: in a row at
@@ -250,6 +255,86 @@ __device__ __forceinline__ float nearest_far(const MapView &M, float qx, float q
   return best;
 }
 
+// Phase 3 from the occupancy tiles (MapView::tiles): the nine words around the home voxel's tile say which of the voxels
+// up to eight away hold points at all -- one round of loads instead of two dependent ones per row of every ring -- and only
+// those are looked up: row by row from the query's row outwards, in a row from the home column outwards, every voxel
+// pruned by its box distance against the best so far (which closes columns, sides and rows as it shrinks).  Voxels
+// farther than eight away are left to the ring walk (nearest_far from ring 9).  Same points, same float32 expression: the
+// minimum is the one nearest_far finds.
+struct FarLds { unsigned row[24][256]; };       // per block of 256 queries: the occupancy bits of the 24 rows around each query
+__device__ __forceinline__ float nearest_far_tiles(const MapView &M, FarLds &F, float qx, float qy, const NearState &S, float best) {
+  if (!S.more) return best;
+  {
+    const double bound = (double)M.leaf * 0.999;
+    if ((double)best <= bound * bound) return best;
+  }
+  const int cx = S.cx, cy = S.cy;
+  const float L = M.leaf;
+  const int tx = cx >> 3, ty = cy >> 3;
+  const unsigned long long *t = M.tiles + (size_t)ty * M.tiles_w + tx;          // tile (tx - 1, ty - 1) of the bordered array
+  unsigned long long w[9];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[3 * r + k] = gld_u64(t + (size_t)r * M.tiles_w + k);
+  // the 24 rows of the 3 x 3 tiles as 24-bit words (bit j = column 8 (tx - 1) + j), cut out once with constant shifts by all
+  // lanes together and kept in LDS: the generator below picks its rows by number
+  unsigned *const rowbits = &F.row[0][threadIdx.x];
+#pragma unroll
+  for (int i = 0; i < 24; ++i) {
+    const int r = i >> 3, sh = (i & 7) << 3;
+    rowbits[i * 256] = ((unsigned)(w[3 * r] >> sh) & 0xffu) | (((unsigned)(w[3 * r + 1] >> sh) & 0xffu) << 8) |
+                       (((unsigned)(w[3 * r + 2] >> sh) & 0xffu) << 16);
+  }
+  const int j0 = 8 + (cx & 7);                                   // the home column in a row's 24 bits
+  const unsigned below = (1u << j0) - 1u;
+  // Every lane runs a generator over its rows (cy, cy - 1, cy + 1, cy - 2, ...) and, inside a row, over the occupied voxels
+  // from the home column outwards; the wave meets once per voxel to be read: finding the next voxel is cheap and differs
+  // from lane to lane (the lanes of a wave come from half a dozen home voxels), reading a voxel's points is the expensive
+  // part and is what all lanes do together.  (With the read inside the row loop a wave executed 5.7k vector instructions
+  // for its 64 queries with 15 lanes active on average.)
+  bool dn_open = true, up_open = true;
+  int step = -1;                                                 // row number in the sequence: 0 -> k = 0; 2k - 1 -> cy - k; 2k -> cy + k
+  unsigned cand = 0;
+  int yy = cy; float by = 0.f;
+  for (int it = 0; it < 24 * 17; ++it) {                         // (a counted loop: at most every voxel of the 17 rows)
+    int cell = -1;
+    while (cell < 0) {
+      if (cand == 0u) {                                          // next row
+        if (++step > 16) break;
+        const int k = (step + 1) >> 1, d = (step != 0 && !(step & 1)) ? 1 : 0;
+        bool &open = d ? up_open : dn_open;
+        by = k == 0 ? 0.f : (d ? S.wu : S.wd) + (float)(k - 1) * L;
+        if (!open || !(by * by < best)) { open = false; if (!dn_open && !up_open) { step = 17; break; } continue; }
+        yy = d ? cy + k : cy - k;
+        cand = rowbits[(yy - ((ty - 1) << 3)) * 256];              // row 0..23 of the 3 x 3 tiles
+        if (k <= 1) cand &= ~(7u << (j0 - 1));                   // the 3 x 3 neighbourhood: phases 1 and 2
+        continue;
+      }
+      if (!(by * by < best)) { cand = 0u; continue; }            // the row has closed since it was opened
+      const unsigned lo = cand & below, hi = cand >> j0;          // left of the home column / from it on
+      const int jl = lo ? 31 - __clz((int)lo) : -64, jr = hi ? j0 + __ffs((int)hi) - 1 : 128;
+      const bool left = (j0 - jl) <= (jr - j0);
+      const int j = left ? jl : jr, dx = j - j0;
+      const float bx = dx < 0 ? S.wl + (float)(-dx - 1) * L : (dx > 0 ? S.wr + (float)(dx - 1) * L : 0.f);
+      if (bx * bx + by * by < best) { cand &= ~(1u << j); cell = yy * M.div_x + cx + dx; }
+      else cand &= left ? ~below : below;                        // whatever is farther out on this side is farther away
+    }
+    if (!__ballot(cell >= 0)) break;                             // (wave-uniform) every generator has run out
+    if (cell >= 0) {
+      const I2u o = ld_i2u(M.pt_start + cell);
+      best = scan_bucket(M.pts, o.x, o.y, qx, qy, best);
+    }
+  }
+  return nearest_far(M, qx, qy, S, best, 8);
+}
+
+// does nearest_far have anything to do for this query?  (its own entry conditions, for the deferred far phase)
+__device__ __forceinline__ bool far_needed(const MapView &M, const NearState &S, float best) {
+  const double bound = (double)M.leaf * 0.999;
+  return S.more && !((double)best <= bound * bound);
+}
+
 __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy) {
   const NearState S = nearest_home(M, qx, qy, nearest_prep(M, qx, qy));
   return nearest_far(M, qx, qy, S, S.more ? nearest_ring1_lane(M, qx, qy, S) : S.best);
@@ -267,11 +352,16 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
 #ifndef NDT_FIT_OCC
 #define NDT_FIT_OCC 6
 #endif
-template <bool SSE>
+// DEFER (launches whose matches share one scan: hypothesis scoring, configs[4]): the queries that need phase 3 are not
+// finished here but put on their match's list -- those with a point in hand from the front, those without from the back --
+// and fitness_far_kernel finishes them, 64 queries of ONE kind per wave.  With phase 3 inline a wave walks the rings of its
+// farthest lane while the others wait: on configs[4]'s seeds the longest lane of a wave needs 31 rounds of dependent loads,
+// the average lane 8, and less than half the lanes need the phase at all.
+template <bool SSE, bool DEFER>
 __global__ void __launch_bounds__(256, NDT_FIT_OCC)
 fitness_points_kernel(MapView M, const float *__restrict__ scans, const unsigned long long *__restrict__ offsets, int B,
                       int shared_scan, const float2 *__restrict__ sorted, const ndt_result *__restrict__ results,
-                      float *__restrict__ fit) {
+                      float *__restrict__ fit, unsigned *__restrict__ far_idx, unsigned *__restrict__ far_n) {
   __shared__ RingLds ring[256 / 64];
   for (int b = blockIdx.y; b < B; b += gridDim.y) {
     const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
@@ -294,8 +384,69 @@ fitness_points_kernel(MapView M, const float *__restrict__ scans, const unsigned
       NearState S = nearest_home(M, qx, qy, nearest_prep(M, qx, qy));
       if (!live) { S.more = false; S.rn[0] = S.rn[1] = S.rn[2] = S.rn[3] = 0; }
       float best = nearest_ring1_wave(M, ring[threadIdx.x >> 6], qx, qy, S);
-      best = nearest_far(M, qx, qy, S, best);
+      if (DEFER) {
+        const bool need = live && far_needed(M, S, best), blind = need && !(best < INFINITY);
+        const unsigned long long ma = __ballot(need && !blind), mb = __ballot(blind);
+        if (ma | mb) {                                           // (wave-uniform) one atomic per wave and kind
+          const int lane = threadIdx.x & 63;
+          unsigned base_a = 0, base_b = 0;
+          if (lane == 0) {
+            if (ma) base_a = atomicAdd(far_n + 2 * (size_t)b, (unsigned)__popcll(ma));
+            if (mb) base_b = atomicAdd(far_n + 2 * (size_t)b + 1, (unsigned)__popcll(mb));
+          }
+          base_a = __builtin_amdgcn_readfirstlane(base_a); base_b = __builtin_amdgcn_readfirstlane(base_b);
+          const unsigned long long below = (1ull << lane) - 1ull;
+          if (need && !blind) far_idx[slot + base_a + (unsigned)__popcll(ma & below)] = (unsigned)i;
+          if (blind) far_idx[slot + (size_t)(n - 1) - (base_b + (unsigned)__popcll(mb & below))] = (unsigned)i;
+        }
+      } else {
+        best = nearest_far(M, qx, qy, S, best);
+      }
       if (i < n) out[i] = live ? best : INFINITY;
+    }
+  }
+}
+
+// Phase 3 of the queries fitness_points_kernel<.., true> has listed: per match the queries with a point in hand, then
+// the ones without (far_n[2b], far_n[2b + 1] of them, from the front / the back of the match's slice of far_idx).
+#ifndef NDT_FAR_OCC
+#define NDT_FAR_OCC 5
+#endif
+template <bool SSE>
+__global__ void __launch_bounds__(256, NDT_FAR_OCC)
+fitness_far_kernel(MapView M, const float *__restrict__ scans, const unsigned long long *__restrict__ offsets, int B,
+                   int shared_scan, const float2 *__restrict__ sorted, const ndt_result *__restrict__ results,
+                   float *__restrict__ fit, const unsigned *__restrict__ far_idx, const unsigned *__restrict__ far_n) {
+  __shared__ FarLds far_lds;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const unsigned na = far_n[2 * (size_t)b], nb = far_n[2 * (size_t)b + 1];
+    if (na + nb == 0u) continue;
+    const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
+    const unsigned long long o1 = shared_scan ? offsets[1] : offsets[b + 1];
+    const int n = (int)(o1 - o0);
+    const ndt_result *R = results + b;
+    const Tf32 T = {R->T00, R->T10, R->T03, R->T13};
+    const bool use_sorted = sorted != nullptr && !(R->flags & NDT_FLAG_UNSORTED);
+    const size_t slot = shared_scan ? (size_t)b * (size_t)n : (size_t)o0;
+    const float2 *pts = use_sorted ? sorted + slot : reinterpret_cast<const float2 *>(scans) + o0;
+    float *out = fit + slot;
+    const unsigned *list = far_idx + slot;
+    // whole waves of one kind: the front list rounded up to waves, then the back list
+    const unsigned wa = (na + 63u) & ~63u, total = wa + nb;
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+      unsigned i;
+      if (e < wa) { if (e >= na) continue; i = list[e]; }
+      else i = list[(unsigned)(n - 1) - (e - wa)];
+      const float2 pt = pts[i];
+      float qx, qy;
+      tf_apply_t<SSE>(T, pt.x, pt.y, qx, qy);
+      NearState S;
+      const int cx0 = (int)floorf(qx * M.inv_leaf) - M.min_bx, cy0 = (int)floorf(qy * M.inv_leaf) - M.min_by;
+      S.cx = cx0 < 0 ? 0 : (cx0 >= M.div_x ? M.div_x - 1 : cx0);
+      S.cy = cy0 < 0 ? 0 : (cy0 >= M.div_y ? M.div_y - 1 : cy0);
+      near_walls(M, qx, qy, S.cx, S.cy, (S.cx == cx0) && (S.cy == cy0), S);
+      S.more = true;
+      out[i] = nearest_far_tiles(M, far_lds, qx, qy, S, out[i]);
     }
   }
 }

@@ -364,7 +364,8 @@ map_finalize_kernel(GridDims G, LeafParams L,
                           const int *__restrict__ start,
                           const float2 *__restrict__ pts, float2 *__restrict__ cent, double *__restrict__ rec,
                           int *__restrict__ npts_grid, int *__restrict__ counters /* unused */,
-                          unsigned *__restrict__ occ /* (ng + 31) / 32 words: voxel in the search set */) {
+                          unsigned *__restrict__ occ /* (ng + 31) / 32 words: voxel in the search set */,
+                          u64 *__restrict__ tiles, int tiles_w /* voxels with raw points, 8 x 8 per word (MapView::tiles) */) {
   const size_t ng = (size_t)G.div_x * G.div_y;
   size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   const bool live = g < ng;
@@ -391,6 +392,8 @@ map_finalize_kernel(GridDims G, LeafParams L,
       }
     }
     flag = write_voxel(G, L, g, n, fx, fy, sx, sy, sxx, sxy, syy, szz, cent, rec, counters);
+    const int vy = (int)(g / (size_t)G.div_x), vx = (int)(g - (size_t)vy * G.div_x);
+    atomicOr(tiles + (size_t)((vy >> 3) + 1) * tiles_w + (vx >> 3) + 1, 1ull << (8 * (vy & 7) + (vx & 7)));
   }
   if (live) npts_grid[g] = flag;
   const u64 in_set = __ballot(flag != 0);       // the wave's 64 consecutive voxels (blockDim is a multiple of 64)
@@ -400,7 +403,10 @@ map_finalize_kernel(GridDims G, LeafParams L,
   }
 }
 
-__global__ void fill_f2_kernel(float2 *p, size_t n, float v) {
+// reset of the centroid grid and of the occupancy tiles (side stream, beside the bucketing chain)
+__global__ void fill_f2_kernel(float2 *p, size_t n, float v, u64 *tiles, size_t ntiles) {
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
     p[i] = make_float2(v, v);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < ntiles; i += (size_t)gridDim.x * blockDim.x)
+    tiles[i] = 0ull;
 }

@@ -76,6 +76,7 @@ struct ndt_ctx {
   void *d_rows = nullptr; size_t d_rows_cap = 0;
   void *d_sorted = nullptr; size_t d_sorted_cap = 0;   // cell-ordered copy of the scans
   void *d_fit = nullptr; size_t d_fit_cap = 0;         // squared distance to the nearest map point, per scan point
+  void *d_far = nullptr; size_t d_far_cap = 0;         // deferred far phase of the fitness search: per match two counts, then the lists
   void *d_ws = nullptr; size_t d_ws_cap = 0;           // WsHeader + ScanCtl[B] + chunk totals
   void *d_pf = nullptr; size_t d_pf_cap = 0;           // pre-filter: filtered points at the raw offsets + counts
   void *d_rn = nullptr; size_t d_rn_cap = 0;           // neighbour removal: block offsets + keep flags
@@ -112,6 +113,7 @@ struct ndt_map {
   unsigned *bounds = nullptr; int *counters = nullptr; int *total = nullptr;   // counters: n_cells, n_valid, n_big
   int *big = nullptr; size_t big_cap = 0;
   unsigned *occ = nullptr; size_t occ_cap = 0;
+  unsigned long long *tiles = nullptr; size_t tiles_cap = 0;   // MapView::tiles
   bool pending = false, pend_queued = false;  // between ndt_map_rebuild_begin and _end
   const float *pend_xy = nullptr; size_t pend_stride = 0;
   GridDims grid; bool have_grid = false;      // voxel grid of the last build (queued ahead of the next one's bounding box)
@@ -255,8 +257,21 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
     const size_t avg = shared_scan ? total_points : (total_points + (size_t)B - 1) / (size_t)B;
     const unsigned gx = (unsigned)std::min<size_t>(64, std::max<size_t>(1, (avg + 255) / 256));
     const dim3 grid(gx, (unsigned)std::min(B, 65535));
-    if (sse) fitness_points_kernel<true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit);
-    else     fitness_points_kernel<false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit);
+    if (shared_scan) {
+      // hypothesis scoring: most seeds end far from the map -- the far phase of the search as a pass of its own over the
+      // queries that need it (ndt_fitness.hip.h)
+      const size_t cnt_bytes = ((size_t)B * 2 * sizeof(unsigned) + 15) & ~(size_t)15;
+      if ((rc = ensure(ctx, &ctx->d_far, &ctx->d_far_cap, cnt_bytes + slots * sizeof(unsigned) + 16))) return rc;
+      unsigned *far_n = (unsigned *)ctx->d_far, *far_idx = (unsigned *)((unsigned char *)ctx->d_far + cnt_bytes);
+      HIP_TRY(ctx, hipMemsetAsync(far_n, 0, cnt_bytes, st));
+      if (sse) fitness_points_kernel<true, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n);
+      else     fitness_points_kernel<false, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n);
+      if (sse) fitness_far_kernel<true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n);
+      else     fitness_far_kernel<false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n);
+    } else {
+      if (sse) fitness_points_kernel<true, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr);
+      else     fitness_points_kernel<false, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr);
+    }
     hipExtLaunchKernelGGL(fitness_reduce_kernel, dim3(std::min(B, 4 * ctx->num_cus)), dim3(kFitBlock), 0, st, nullptr, evr[2], 0,
                           offsets, B, shared_scan, (const float *)fit, out, (uint4 *)ws, (unsigned)(zero_bytes / 16));
   }
@@ -388,7 +403,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->ev_scratch) e = hipEventDestroy(c->ev_scratch);
   for (hipEvent_t r : c->ev_ring) if (r) e = hipEventDestroy(r);
   if (c->h_mm) e = hipHostFree(c->h_mm);
-  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_fit, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
+  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_fit, c->d_far, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
   delete c;
@@ -462,7 +477,7 @@ int ndt_map_destroy(ndt_map *m) {
   }
   e = hipStreamSynchronize(m->ctx->stream);
   if (m->ctx->side) e = hipStreamSynchronize(m->ctx->side);
-  void *bufs[] = {m->occ, m->big, m->count, m->start, m->tile, m->npts_grid, m->perm, m->perm_sorted, m->pts,
+  void *bufs[] = {m->occ, m->tiles, m->big, m->count, m->start, m->tile, m->npts_grid, m->perm, m->perm_sorted, m->pts,
                   m->cent, m->rec, m->bounds, m->counters, m->total, m->d_xy_stage};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
@@ -478,6 +493,8 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   const float inv_leaf = G.inv_leaf;
   const size_t ng = (size_t)G.div_x * G.div_y, npad = (size_t)G.gw * G.gh;
   m->ng = ng; m->npad = npad;
+  const int tiles_w = (G.div_x + 7) / 8 + 2, tiles_h = (G.div_y + 7) / 8 + 2;
+  const size_t ntile8 = (size_t)tiles_w * tiles_h;
 
   // 2. buffers (grow-only across rebuilds)
   {
@@ -492,6 +509,7 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
     if ((rc = ensure_t(ctx, &m->perm, &m->perm_cap, n))) return rc;
     if ((rc = ensure_t(ctx, &m->big, &m->big_cap, n / kBigVoxel + 1))) return rc;   // voxels with > kBigVoxel points
     if ((rc = ensure_t(ctx, &m->occ, &m->occ_cap, (ng + 31) / 32 + 2))) return rc;
+    if ((rc = ensure_t(ctx, &m->tiles, &m->tiles_cap, ntile8))) return rc;
     if ((rc = ensure_t(ctx, &m->pts, &m->pts_cap, n))) return rc;
     if ((rc = ensure_t(ctx, &m->cent, &m->cent_cap, npad))) return rc;
     if ((rc = ensure_t(ctx, &m->rec, &m->rec_cap, npad * 8))) return rc;
@@ -511,7 +529,7 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
     HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
     HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
   }
-  fill_f2_kernel<<<grid_for(npad, 256), 256, 0, ctx->side>>>(m->cent, npad, INFINITY);
+  fill_f2_kernel<<<grid_for(npad, 256), 256, 0, ctx->side>>>(m->cent, npad, INFINITY, m->tiles, ntile8);
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
 
   // 3. bucket the points by voxel, cloud order kept inside a bucket
@@ -536,7 +554,7 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   L.eig_mult = prm->eig_mult;
   map_finalize_kernel<<<(unsigned)((ng + 255) / 256), 256, 0, st>>>(G, L, start,
                                                                           m->pts, m->cent, m->rec, m->npts_grid,
-                                                                          m->counters, m->occ);
+                                                                          m->counters, m->occ, m->tiles, tiles_w);
   HIP_TRY(ctx, hipGetLastError());
 
   MapView &V = m->view;
@@ -544,7 +562,7 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   V.r2 = (float)((double)prm->resolution * (double)prm->resolution);
   V.radius_inclusive = prm->radius_inclusive; V.transform_sse = prm->transform_sse;
   V.min_bx = G.min_bx; V.min_by = G.min_by; V.div_x = G.div_x; V.div_y = G.div_y; V.gw = G.gw; V.gh = G.gh;
-  V.cent = m->cent; V.rec = m->rec; V.occ = m->occ; V.pt_start = start; V.pts = m->pts;
+  V.cent = m->cent; V.rec = m->rec; V.occ = m->occ; V.tiles = m->tiles; V.tiles_w = tiles_w; V.pt_start = start; V.pts = m->pts;
   gauss_constants(*prm, &V.d1, &V.d2);
   V.e_hi = pair_check_threshold(V.d2);
   m->info.min_bx = G.min_bx; m->info.min_by = G.min_by; m->info.div_x = G.div_x; m->info.div_y = G.div_y;

@@ -257,6 +257,47 @@ def test_batch_fitness_ring_phase_matches_the_single_query_search(gpu, oracle):
             assert r["fitness"] == pytest.approx(om.fitness(sc, r["T00"], r["T10"], r["T03"], r["T13"]), rel=1e-13)
 
 
+def test_far_phase_from_the_occupancy_tiles_matches_the_ring_walk(gpu, oracle):
+    """Launches whose matches share one scan (`shared_scan`: hypothesis scoring) finish the queries that are more than a
+    voxel away from every map point in a kernel of their own, from the 8 x 8-voxel occupancy words of the map
+    (ndt_fitness.hip.h, fitness_far_kernel / nearest_far_tiles); every other launch walks ring after ring inside the search
+    kernel (nearest_far), and `ndt_fitness_at` is the plain per-query search.  Same points, same float32 expression: the three
+    must agree to the last bit of every distance: the two batch paths add them in the same order and are compared for
+    equality, `ndt_fitness_at` and the oracle (another order of the sum) to 1e-13.  max_iter = 0 keeps every match at
+    its seed pose: seeds 0.3 m .. 30 m off (beyond the eight voxels the words cover: the ring walk takes over), rotated, and
+    far outside the map's bounding box (queries clamped into the grid), on a scan with NaN points."""
+    capi, ctx = gpu
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C2"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    scan, truth, _ = sf.make(3)
+    scan = scan[:9973].copy(); scan[[7, 65, 4099, 9972]] = np.nan
+    rng = np.random.default_rng(11)
+    shifts = np.array([0.3, 0.7, 1.2, 2.0, 3.1, 4.5, 6.0, 9.0, 14.0, 30.0, 2.0 * cfg["half"], -2.5 * cfg["half"]])
+    seeds = []
+    for sh in shifts:
+        for _ in range(3):
+            ang = rng.uniform(0, 2 * np.pi)
+            seeds.append([truth[0] + sh * np.cos(ang), truth[1] + sh * np.sin(ang), truth[2] + rng.uniform(-0.5, 0.5)])
+    seeds = np.array(seeds)
+    B = len(seeds)
+    prm = capi.default_params(resolution=cfg["resolution"], max_iter=0)
+    gm = capi.Map(ctx, m, prm)
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"], max_iter=0))
+    off1 = np.array([0, len(scan)], np.uint64)
+    shared = gm.align_batch(scan, off1, seeds, shared_scan=True)                        # tiles, kernel of its own
+    tiled = gm.align_batch(np.tile(scan, (B, 1)), (np.arange(B + 1) * len(scan)).astype(np.uint64), seeds)   # ring walk, inline
+    assert np.all(shared["status"] == 0) and np.all(tiled["status"] == 0)
+    assert shared["fitness"].tobytes() == tiled["fitness"].tobytes()
+    assert shared.tobytes() == tiled.tobytes()
+    for b in range(0, B, 2):
+        r = shared[b]
+        assert r["fitness"] == pytest.approx(gm.fitness_at(scan, r["T00"], r["T10"], r["T03"], r["T13"]), rel=1e-13), b
+        assert r["fitness"] == pytest.approx(om.fitness(scan, r["T00"], r["T10"], r["T03"], r["T13"]), rel=1e-13), b
+    assert shared["fitness"].max() > 100.0 and shared["fitness"].min() < 0.2         # the cases span what they claim to
+
+
 # ------------------------------------------------------------------------------------------ a3-a9
 def test_c1_matches_oracle_with_same_step_sequence(gpu, oracle, c1_world):
     """BASELINE.json configs[0]: 360-pt scan vs 5k-pt map, launch-file parameters."""
