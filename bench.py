@@ -404,7 +404,7 @@ def main():
                                  "own, listed under `fitness`",
                          "kernel": "ndt_align_kernel", "kernel_ms": avg_kern_ms,
                          "launch_interval_ms": float(np.mean(kern_ms)) if kern_ms else None,
-                         "fitness": {"kernels": "fitness_points_kernel + fitness_reduce_kernel", "ms": fit_ms,
+                         "fitness": {"kernels": "fitness_points_kernel + fitness_far_kernel + fitness_reduce_kernel" if c5 else "fitness_points_kernel + fitness_reduce_kernel", "ms": fit_ms,
                                      "algorithmic_bytes_per_launch": fit_bytes,
                                      "achieved_GBps": fit_bytes / (fit_ms * 1e-3) / 1e9 if fit_ms > 0 else None},
                          "algorithmic_bytes_per_launch": alg_bytes,
