@@ -94,6 +94,20 @@ __device__ __forceinline__ double2 gld_d2(const double *p) {
 }
 __device__ __forceinline__ double gld_d(const double *p) { return *(const NDT_GLOBAL double *)p; }
 __device__ __forceinline__ int gld_i(const int *p) { return *(const NDT_GLOBAL int *)p; }
+// Inclusive prefix sum over the 64 lanes of a wave with DPP moves only (row shifts with zero fill, then the row totals
+// carried into the next rows): no LDS round trips.
+__device__ __forceinline__ unsigned wave_incl_scan(unsigned x) {
+#define NDT_DPP_ADD(CTRL, ROWS) x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xF, true)
+  NDT_DPP_ADD(0x111, 0xF);     // row_shr:1
+  NDT_DPP_ADD(0x112, 0xF);     // row_shr:2
+  NDT_DPP_ADD(0x114, 0xF);     // row_shr:4
+  NDT_DPP_ADD(0x118, 0xF);     // row_shr:8
+  NDT_DPP_ADD(0x142, 0xA);     // row_bcast15: the total of rows 0 / 2 into rows 1 / 3
+  NDT_DPP_ADD(0x143, 0xC);     // row_bcast31: the total of rows 0 + 1 into rows 2, 3
+#undef NDT_DPP_ADD
+  return x;
+}
+
 __device__ __forceinline__ unsigned long long gld_u64(const unsigned long long *p) { return *(const NDT_GLOBAL unsigned long long *)p; }
 
 __device__ __forceinline__ float2 load_pt(const float *xy, size_t stride, size_t i) {

@@ -175,9 +175,7 @@ __device__ __forceinline__ float nearest_ring1_wave(const MapView &M, RingLds &R
   // many lanes with work of their own (poorly matched scans): each walks its own sequence, all lanes busy anyway
   if (K > kRingJointMax) return need ? nearest_ring1_lane(M, qx, qy, S) : S.best;
   const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-  int incl = T;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+  const int incl = (int)wave_incl_scan((unsigned)T);             // (DPP moves: no LDS round trips)
   const int W = __builtin_amdgcn_readlane(incl, 63);             // (query, point) pairs of the wave
   if (need) {
     const int c1 = S.rn[0], c2 = c1 + S.rn[1], c3 = c2 + S.rn[2];

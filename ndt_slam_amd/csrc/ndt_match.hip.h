@@ -559,20 +559,6 @@ __device__ __noinline__ bool sort_points(const MapView &M, const Tf32 &T0, const
   return true;
 }
 
-// Inclusive prefix sum over the 64 lanes of a wave with DPP moves only (row shifts with zero fill, then the row totals
-// carried into the next rows): no LDS round trips.
-__device__ __forceinline__ unsigned wave_incl_scan(unsigned x) {
-#define NDT_DPP_ADD(CTRL, ROWS) x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xF, true)
-  NDT_DPP_ADD(0x111, 0xF);     // row_shr:1
-  NDT_DPP_ADD(0x112, 0xF);     // row_shr:2
-  NDT_DPP_ADD(0x114, 0xF);     // row_shr:4
-  NDT_DPP_ADD(0x118, 0xF);     // row_shr:8
-  NDT_DPP_ADD(0x142, 0xA);     // row_bcast15: the total of rows 0 / 2 into rows 1 / 3
-  NDT_DPP_ADD(0x143, 0xC);     // row_bcast31: the total of rows 0 + 1 into rows 2, 3
-#undef NDT_DPP_ADD
-  return x;
-}
-
 // Owner: optimiser start + window geometry + spatial order of a scan of at most PER * kBlock points in ONE routine that
 // keeps the scan in registers (round 3; compute_region + sort_points below remain for longer scans).  The separate
 // routines read the scan from memory four times -- bounding box, histogram, scatter, and a gather by point number in the
