@@ -171,7 +171,9 @@ int ndt_align(ndt_ctx *ctx, const ndt_map *map, const float *scan_xy_host, size_
 
 /* Batch of B independent matches against one map (BASELINE.json configs 3-5).  Scans are
  * packed float2, concatenated; offsets[B+1] in points.  shared_scan != 0: every match uses
- * scan 0 (offsets[0..1]) with its own init pose (multi-hypothesis relocalisation). */
+ * scan 0 (offsets[0..1]) with its own init pose (multi-hypothesis relocalisation).  Such launches keep a scratch
+ * slot of the scan's size PER MATCH (ordered copy 8 B, distance 4 B, far-query list 4 B per point: 16 B x n x B)
+ * and score the seeds that end far from the map from the map's occupancy words (same `fitness`). */
 int ndt_align_batch(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_host,
                     const uint64_t *offsets_host, int B, int shared_scan,
                     const double *inits_host /* B x 3 */, ndt_result *out_host /* B */);
