@@ -980,12 +980,15 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
   // ran (tests/test_gpu_robustness.py: 20 ms).  Now a workgroup that has used the queue up first looks for a scan nobody
   // has claimed and takes it over; the late workgroup finds its scan taken and moves on: no wait in the kernel depends
   // on a workgroup that is not running.  (Scans of the queue are handed out by a counter to workgroups that are running.)
-  // Not covered: with B < gridDim.x the workgroups numbered >= B start as helpers and never look for an unclaimed scan,
-  // so a scan whose own workgroup is held back while higher-numbered ones run waits for that workgroup -- a delay of the
-  // foreign kernel's length, not a hang.  Workgroups are dispatched in ascending order per XCD, so it takes a foreign
-  // kernel that fills one whole XCD and leaves another free; tests/test_gpu_robustness.py runs B = 24 beside the hog.
+  // With fewer scans than workgroups the first 4 B workgroups bid for a scan each -- workgroup j B + r for scan (r + j) mod B,
+  // so that a scan's (up to) four bidders sit on different XCDs: whichever of them is resident first owns the scan, the
+  // others find it taken and help (results do not depend on the owner); a scan waits for a workgroup that is not running
+  // only if NONE of its bidders is.  tests/test_gpu_robustness.py: B = 24.
   int preclaimed = -1;
-  for (int b = blockIdx.x; b < B && !aborted;) {
+  int b0 = (int)blockIdx.x;
+  if (allow_helpers && B > 0 && B < (int)gridDim.x && blockIdx.x < 4u * (unsigned)B)
+    b0 = (int)((blockIdx.x % (unsigned)B + blockIdx.x / (unsigned)B) % (unsigned)B);
+  for (int b = b0; b < B && !aborted;) {
     const u64 o0 = shared_scan ? offsets[0] : offsets[b];
     const u64 o1 = shared_scan ? offsets[1] : offsets[b + 1];
     const int n = (int)(o1 - o0);
