@@ -43,6 +43,9 @@ constexpr int kDefaultHelpers = 8;
 #ifndef NDT_IDLE_MAX
 #define NDT_IDLE_MAX 800           // idle helper back-off: 4 us doubling up to 8 us (100 MHz ticks)
 #endif
+#ifndef NDT_XCD_BONUS
+#define NDT_XCD_BONUS 6          // passes' worth of preference for scans owned on the helper's own XCD (0: off)
+#endif
 #ifndef NDT_HELPER_PENALTY
 #define NDT_HELPER_PENALTY 12    // passes a scan must be ahead by before it gets one more helper than another
 #endif
@@ -115,7 +118,8 @@ struct alignas(128) ScanCtl {
   u32 ready;         //         helpers whose window is staged; rank = order of registration
   u32 use_sorted;    //         1: passes read the scan from the sorted scratch copy
   u32 claimed;       //         1: a workgroup owns this scan (compare-and-swap; see "claims" in the kernel)
-  int pad2_[21];
+  u32 owner_xcd;     //         1 + XCD of the owning workgroup (helpers of the same XCD share its L2)
+  int pad2_[20];
 };
 static_assert(sizeof(ScanCtl) == 256, "ScanCtl is two 128-byte lines");
 
@@ -1006,6 +1010,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
                        __hip_atomic_compare_exchange_strong(&C->claimed, &expect, 1u, NDT_RLX, NDT_RLX, NDT_AGENT);
       L.sflag[3] = won ? 1 : 0;
       if (won) {
+        if (NDT_XCD_BONUS && allow_helpers) st32(&C->owner_xcd, 1u + (blockIdx.x & 7u));
         if (!reg_path) init_state(L.S, L.P, inits + 3 * (size_t)b, (double)n);
         if (trace_rows) trace_rows[b] = 0;
         if (n <= 0) { L.S.phase = PH_DONE; L.S.converged = 0; }
@@ -1312,7 +1317,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       if (h >= (u32)room) continue;
       // a scan that already needed many passes will likely need many more: most passes first,
       // each attached helper counting like 4 passes fewer; then nearest
-      const int score = (int)min(ld32(&ctl[b].passes), 200u) - NDT_HELPER_PENALTY * (int)h;
+      const int score = (int)min(ld32(&ctl[b].passes), 200u) - NDT_HELPER_PENALTY * (int)h +
+                        ((NDT_XCD_BONUS && ld32(&ctl[b].owner_xcd) == 1u + (blockIdx.x & 7u)) ? NDT_XCD_BONUS : 0);
       atomicMin(&L.sflag[0], (int)(((u32)(512 - score) << 20) | (u32)k));
     }
     __syncthreads();
