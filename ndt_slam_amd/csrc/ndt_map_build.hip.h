@@ -237,17 +237,33 @@ constexpr int kOrderVoxPerBlock = 256 / 8 * 4;     // 32 lane groups, 4 voxels e
 __device__ __forceinline__ void order_small_voxels(unsigned block, const int *__restrict__ start, size_t ng,
                                                    const int *__restrict__ perm, const float *__restrict__ xy, size_t stride,
                                                    float2 *__restrict__ pts) {
-  const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  // A group of eight lanes takes four voxels.  The kernel is a chain of dependent loads (offsets -> numbers -> point) on mostly
+  // EMPTY voxels, so the four voxels are walked side by side: their offsets in one round (a lane each), then their numbers, then
+  // their points, instead of four chains one after the other.
+  const int grp = threadIdx.x >> 3, sub = threadIdx.x & 7, lane = threadIdx.x & 63;
+  const size_t g0 = (size_t)block * kOrderVoxPerBlock + (size_t)grp * 4;
+  int my_s = 0, my_n = 0;
+  if (sub < 4 && g0 + sub < ng) { my_s = start[g0 + sub]; my_n = start[g0 + sub + 1] - my_s; }
+  int s0[4], n[4], nmax = 0;
+#pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const size_t g = (size_t)block * kOrderVoxPerBlock + (size_t)r * 32 + grp;
-    if (g >= ng) return;
-    const int s0 = start[g], n = start[g + 1] - s0;
-    if (n > kBigVoxel) continue;
-    for (int e = sub; e < n; e += 8) {
-      const int mine = perm[s0 + e];
+    s0[r] = __shfl(my_s, (lane & ~7) + r); n[r] = __shfl(my_n, (lane & ~7) + r);
+    if (n[r] > kBigVoxel) n[r] = 0;                          // (listed for the wave-per-voxel workgroups)
+    nmax = max(nmax, n[r]);
+  }
+  for (int e = sub; e < nmax; e += 8) {
+    int mine[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mine[r] = e < n[r] ? perm[s0[r] + e] : 0;
+    float2 p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) p[r] = e < n[r] ? load_pt(xy, stride, (size_t)mine[r]) : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (e >= n[r]) continue;
       int rank = 0;
-      for (int j = 0; j < n; ++j) rank += (perm[s0 + j] < mine) ? 1 : 0;
-      pts[s0 + rank] = load_pt(xy, stride, (size_t)mine);   // the point itself goes to its place: map_finalize_kernel streams them
+      for (int j = 0; j < n[r]; ++j) rank += (perm[s0[r] + j] < mine[r]) ? 1 : 0;
+      pts[s0[r] + rank] = p[r];                              // the point itself goes to its place: map_finalize_kernel streams them
     }
   }
 }
