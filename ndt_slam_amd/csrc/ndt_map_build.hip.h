@@ -393,10 +393,16 @@ map_finalize_kernel(GridDims G, LeafParams L,
     float fx = 0.f, fy = 0.f;
     double sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0, szz = 0;
     if (L.cov_init_identity) { sxx = 1.0; syy = 1.0; szz = 1.0; }
-    for (int s = s0; s < s1; s += 8) {          // eight loads in flight, consecutive addresses (map_order_kernel put the points in cloud order)
-      float2 pb[8];
+    // eight loads in flight, consecutive addresses (map_order_kernel put the points in cloud order), and the NEXT eight issued
+    // before these are added up: the kernel ends with its fullest voxel, whose sums are one dependent chain by definition
+    float2 pb[8], pn[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) pb[u] = pts[min(s + u, s1 - 1)];
+    for (int u = 0; u < 8; ++u) pb[u] = pts[min(s0 + u, s1 - 1)];
+    for (int s = s0; s < s1; s += 8) {
+      if (s + 8 < s1) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pn[u] = pts[min(s + 8 + u, s1 - 1)];
+      }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (s + u >= s1) break;
@@ -406,6 +412,8 @@ map_finalize_kernel(GridDims G, LeafParams L,
         sx += X; sy += Y;
         sxx += X * X; sxy += X * Y; syy += Y * Y;
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pb[u] = pn[u];
     }
     flag = write_voxel(G, L, g, n, fx, fy, sx, sy, sxx, sxy, syy, szz, cent, rec, counters);
     const int vy = (int)(g / (size_t)G.div_x), vx = (int)(g - (size_t)vy * G.div_x);
