@@ -262,13 +262,20 @@ __device__ __forceinline__ void order_small_voxels(unsigned block, const int *__
     for (int r = 0; r < 4; ++r) {
       if (e >= n[r]) continue;
       int rank = 0;
-      for (int j = 0; j < n[r]; ++j) rank += (perm[s0[r] + j] < mine[r]) ? 1 : 0;
+      // four numbers per load; what is read past the end of the bucket (perm has four spare entries) does not count
+      for (int j = 0; j < n[r]; j += 4) {
+        const ndt_i4v q = *(const NDT_GLOBAL ndt_i4v_u *)(perm + s0[r] + j);
+        rank += (q.x < mine[r]) ? 1 : 0;
+        rank += (j + 1 < n[r] && q.y < mine[r]) ? 1 : 0;
+        rank += (j + 2 < n[r] && q.z < mine[r]) ? 1 : 0;
+        rank += (j + 3 < n[r] && q.w < mine[r]) ? 1 : 0;
+      }
       pts[s0[r] + rank] = p[r];                              // the point itself goes to its place: map_finalize_kernel streams them
     }
   }
 }
 
-constexpr int kBigWavesPerBlock = 4, kBigBlocks = 1024, kBigStage = 512;   // LDS staging: point numbers per wave
+constexpr int kBigWavesPerBlock = 4, kBigBlocks = 4096, kBigStage = 512;   // LDS staging: point numbers per wave
 // One launch for both kinds (they do not depend on each other): workgroups [0, small_blocks) take the small voxels,
 // the kBigBlocks behind them the listed big ones.
 __global__ void __launch_bounds__(256)

@@ -506,7 +506,7 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
     if ((rc = ensure_t(ctx, &m->start, &m->start_cap, ng + 1 + 8))) return rc;   // 4 readable ints before, 3 after (nearest_sq)
     if ((rc = ensure_t(ctx, &m->npts_grid, &m->npts_cap, ng + 1))) return rc;
     if ((rc = ensure_t(ctx, &m->tile, &m->tile_cap, ntiles_ + 1))) return rc;
-    if ((rc = ensure_t(ctx, &m->perm, &m->perm_cap, n))) return rc;
+    if ((rc = ensure_t(ctx, &m->perm, &m->perm_cap, n + 4))) return rc;       // + 4: map_order_kernel reads four numbers at a time
     if ((rc = ensure_t(ctx, &m->big, &m->big_cap, n / kBigVoxel + 1))) return rc;   // voxels with > kBigVoxel points
     if ((rc = ensure_t(ctx, &m->occ, &m->occ_cap, (ng + 31) / 32 + 2))) return rc;
     if ((rc = ensure_t(ctx, &m->tiles, &m->tiles_cap, ntile8))) return rc;
