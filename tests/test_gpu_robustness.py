@@ -35,7 +35,7 @@ def hog(tmp_path_factory):
     return L
 
 
-@pytest.mark.parametrize("B", [256, 24])
+@pytest.mark.parametrize("B", [256, 24, 1])
 def test_match_launches_beside_foreign_queues(hog, B):
     import torch
     from ndt_slam_amd import capi, synth
