@@ -538,6 +538,20 @@ int ndt_oracle_mt_update(double *a_l, double *f_l, double *g_l, double *a_u, dou
   return 1;
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* pin hooks (tests only): let a test substitute the reference's vendored Eigen, compiled in   */
+/* the build container (tests/golden/make_eigen_golden.cpp), for the hand restatements below,  */
+/* so that a whole match can be replayed with the Eigen-exact step.  Not thread safe.          */
+/* ------------------------------------------------------------------------------------------ */
+static ndt_oracle_hooks g_hooks = {0, 0};
+void ndt_oracle_set_hooks(const ndt_oracle_hooks *h) {
+  if (h) g_hooks = *h; else { g_hooks.solve = 0; g_hooks.init_p = 0; }
+}
+static void newton_solve(const double H[9], const double b[3], double x[3]) {
+  if (g_hooks.solve) g_hooks.solve(H, b, x); else ndt_oracle_solve3(H, b, x);
+}
+
 typedef struct {
   const ndt_oracle_map *m;
   const float *scan; size_t n, stride;
@@ -681,6 +695,18 @@ double ndt_oracle_fitness(const ndt_oracle_map *m, const float *scan, size_t n, 
   return fitness_pass(m, scan, n, stride, T);
 }
 
+/* src/PoseEstimator.cpp:22-24 init_guess = Translation3f(tx,ty,0) * AngleAxisf(yaw, Z), then the
+ * computeTransformation prologue: p = (translation, rotation().eulerAngles(0,1,2)) of the float matrix;
+ * for a pure-Z rotation eulerAngles gives (-0, 0, atan2f(s, c)) (include/Eigen/src/Geometry/EulerAngles.h:87-107).
+ * tests/test_eigen_pins.py holds this against the vendored Eigen's own answer. */
+static void init_guess(const double init[3], tf32 *T, double p[3]) {
+  double pinit[3] = {init[0], init[1], init[2]};
+  *T = tf_from_p(pinit);
+  p[0] = (double)T->tx; p[1] = (double)T->ty;
+  p[2] = (double)(float)atan2((double)T->s, (double)T->c);
+  if (g_hooks.init_p) { float t4[4] = {T->c, T->s, T->tx, T->ty}; g_hooks.init_p(t4, p); }
+}
+
 /* src/PoseEstimator.cpp:17-64 with the source cloud already filtered (a1 upstream). */
 int ndt_oracle_align(const ndt_oracle_map *m, const float *scan, size_t n, size_t stride,
                      const double init[3], ndt_oracle_result *res, double *trace, int trace_cap) {
@@ -693,12 +719,8 @@ int ndt_oracle_align(const ndt_oracle_map *m, const float *scan, size_t n, size_
   cx.trace = trace; cx.trace_cap = trace_cap;
 
   /* src/PoseEstimator.cpp:22-24: init_guess = Translation3f(tx,ty,0) * AngleAxisf(yaw, Z) */
-  double pinit[3] = {init[0], init[1], init[2]};
-  cx.T = tf_from_p(pinit);
-  /* computeTransformation prologue: p = (translation, eulerAngles(0,1,2)) of the float matrix;
-   * for a pure-Z rotation eulerAngles gives (-0, 0, atan2f(s, c))
-   * (include/Eigen/src/Geometry/EulerAngles.h:87-107). */
-  double p[3] = {(double)cx.T.tx, (double)cx.T.ty, (double)(float)atan2((double)cx.T.s, (double)cx.T.c)};
+  double p[3];
+  init_guess(init, &cx.T, p);
   transform_scan(prm, scan, n, stride, cx.T, cx.trans);   /* transformPointCloud(output, output, guess) */
 
   double g[3], H[6], score;
@@ -709,7 +731,7 @@ int ndt_oracle_align(const ndt_oracle_map *m, const float *scan, size_t n, size_
   while (!converged) {
     double Hf[9] = {H[0], H[1], H[2], H[1], H[3], H[4], H[2], H[4], H[5]};
     double mg[3] = {-g[0], -g[1], -g[2]}, dp[3];
-    ndt_oracle_solve3(Hf, mg, dp);
+    newton_solve(Hf, mg, dp);
     double nrm = sqrt(dp[0] * dp[0] + dp[1] * dp[1] + dp[2] * dp[2]);
     if (nrm == 0 || nrm != nrm) { converged = (nrm == nrm); nan_exit = 1; break; }
     dp[0] /= nrm; dp[1] /= nrm; dp[2] /= nrm;
@@ -943,4 +965,44 @@ size_t ndt_oracle_remove_neighbors(const float *base, size_t nb, const float *li
     if (flag) { out[2 * cnt] = base[2 * i]; out[2 * cnt + 1] = base[2 * i + 1]; ++cnt; }
   }
   return cnt;
+}
+
+
+/* ------------------------------------------------------------------------------------------
+ * Pin points: the hand restatements of routines whose source IS in the reference tree (its vendored
+ * Eigen 3.3.90), exposed one by one for tests/test_eigen_pins.py (fixtures: tests/golden/eigen_golden.npz,
+ * made by tests/golden/make_eigen_golden.{cpp,py} from that Eigen).
+ * ------------------------------------------------------------------------------------------ */
+int ndt_oracle_leaf(const ndt_oracle_params *prm, int n, const double sums[6], double mean[2], double icov[3]) {
+  return leaf_finalize(prm, n, sums[0], sums[1], sums[2], sums[3], sums[4], sums[5], mean, icov);
+}
+void ndt_oracle_inv3(const double m[9], double out[9]) { f2_inv3(m, out); }
+void ndt_oracle_init_guess(const double init[3], float T[4], double p[3]) {
+  tf32 t; init_guess(init, &t, p);
+  T[0] = t.c; T[1] = t.s; T[2] = t.tx; T[3] = t.ty;
+}
+void ndt_oracle_step_matrix(const double p[3], float T[4]) {
+  tf32 t = tf_from_p(p);
+  T[0] = t.c; T[1] = t.s; T[2] = t.tx; T[3] = t.ty;
+}
+/* replace the fp64 part of the cell table (compact order of ndt_oracle_map_export) */
+void ndt_oracle_map_override_cells(ndt_oracle_map *m, const double *mean, const double *icov, const int *npts) {
+  memcpy(m->c_mean, mean, 2 * (size_t)m->n_cells * sizeof(double));
+  memcpy(m->c_icov, icov, 3 * (size_t)m->n_cells * sizeof(double));
+  if (npts) memcpy(m->c_npts, npts, (size_t)m->n_cells * sizeof(int));
+}
+/* per-voxel sums exactly as the build loop forms them (cloud order, fp64; identity start per preset):
+ * n_cells x {n, sx, sy, sxx, sxy, syy, szz} */
+void ndt_oracle_map_export_sums(const ndt_oracle_map *m, double *out) {
+  for (int c = 0; c < m->n_cells; ++c) {
+    int g = m->c_idx[c];
+    double sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0, szz = 0;
+    if (m->prm.cov_init_identity) { sxx = 1.0; syy = 1.0; szz = 1.0; }
+    for (int s = m->pt_start[g]; s < m->pt_start[g + 1]; ++s) {
+      double X = (double)m->pts[2 * s], Y = (double)m->pts[2 * s + 1];
+      sx += X; sy += Y; sxx += X * X; sxy += X * Y; syy += Y * Y;
+    }
+    double *o = out + 7 * (size_t)c;
+    o[0] = (double)(m->pt_start[g + 1] - m->pt_start[g]); o[1] = sx; o[2] = sy; o[3] = sxx; o[4] = sxy; o[5] = syy; o[6] = szz;
+  }
 }

@@ -187,6 +187,21 @@ size_t ndt_oracle_difference_extraction(const float *base_xy, size_t n_base, con
 size_t ndt_oracle_make_map(const float *scans_xy, const size_t *offsets, int n_scans, int first_submap, int newest,
                            int remove_moving, double resol, double thre_neighbor, float *out_xy);
 
+
+/* ---- pin points and hooks (tests/test_eigen_pins.py; see the end of ndt_oracle.c) ---- */
+typedef struct ndt_oracle_hooks {
+  void (*solve)(const double H[9], const double b[3], double x[3]);   /* replaces ndt_oracle_solve3 in the Newton step */
+  void (*init_p)(const float T[4] /* c, s, tx, ty */, double p[3]);     /* may overwrite the initial parameter vector  */
+} ndt_oracle_hooks;
+void ndt_oracle_set_hooks(const ndt_oracle_hooks *h);                   /* NULL: none.  Not thread safe */
+int  ndt_oracle_leaf(const ndt_oracle_params *prm, int n, const double sums[6] /* sx sy sxx sxy syy szz */,
+                     double mean[2], double icov[3]);                   /* 1 accepted, 0 / -1 rejected */
+void ndt_oracle_inv3(const double m[9], double out[9]);
+void ndt_oracle_init_guess(const double init[3], float T[4], double p[3]);
+void ndt_oracle_step_matrix(const double p[3], float T[4]);
+void ndt_oracle_map_override_cells(ndt_oracle_map *m, const double *mean, const double *icov, const int *npts);
+void ndt_oracle_map_export_sums(const ndt_oracle_map *m, double *out /* n_cells x 7 */);
+
 #ifdef __cplusplus
 }
 #endif
