@@ -101,6 +101,10 @@ def main():
     ap.add_argument("--max-helpers", type=int, default=-1, help="helper workgroups per unfinished scan (default: the library's 8); fewer free CUs earlier for whatever is queued behind the launch")
     ap.add_argument("--time-builds", action="store_true", help="extra events around the map build and around the whole launch inside the step loop (launch_interval_ms, map_build_in_step_ms)")
     ap.add_argument("--no-scatter", action="store_true", help="N > 1: every rank generates its own shard instead of receiving it from rank 0")
+    ap.add_argument("--map-from-rank0", action="store_true", help="N > 1: only rank 0 generates the target cloud, the others build their map from shard.broadcast_map's copy (by default every rank generates it AND the broadcast is timed and checked against it: comm.broadcast_map_ms)")
+    ap.add_argument("--moving-steps", type=int, default=48, help="steps of the moving-local-map side leg (0: skip)")
+    ap.add_argument("--moving-every", type=int, default=8, help="moving-local-map leg: the cloud's voxel bounding box moves every k-th step")
+    ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state side figure (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-single-scan", action="store_true", help="skip the side figures (configs[1] latency, C5 leg, rows f1-f3)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="matches timed on the host cores")
@@ -146,7 +150,31 @@ def main():
     comm = {}
 
     # ---------------------------------------------------------------- inputs (synthetic: the reference ships no data)
-    map_xy = synth.make_map(cfg["n_map"], cfg["half"])          # the same map on every rank (built redundantly)
+    # The target cloud.  Every rank BUILDS its own cell table ("build redundantly from a broadcast of raw
+    # points"); where the raw points come from at N > 1: by default every rank generates the same synthetic cloud and the
+    # fan-out a caller with ONE PointCloudMap needs (src/ScanMatcher.cpp:40) -- shard.broadcast_map, chunked -- is timed
+    # and checked against it byte for byte; with --map-from-rank0 only rank 0 generates and the others use the copy.
+    map_xy = synth.make_map(cfg["n_map"], cfg["half"]) if (rank == 0 or not args.map_from_rank0) else None
+    if world > 1:
+        try:
+            fence()
+            t0 = time.perf_counter()
+            t_map = shard.broadcast_map(map_xy if rank == 0 else None, src=0, device=comm_dev)
+            fence()
+            comm["broadcast_map_ms"] = (time.perf_counter() - t0) * 1e3
+            comm["broadcast_map_bytes"] = int(t_map.numel() * 4)
+            got = t_map.cpu().numpy()
+            if map_xy is None:
+                map_xy = got
+            else:
+                same = torch.tensor([1 if got.tobytes() == map_xy.tobytes() else 0], dtype=torch.int64, device=comm_dev)
+                dist.all_reduce(same, op=dist.ReduceOp.MIN)
+                comm["broadcast_map_identical_on_every_rank"] = bool(int(same.item()))
+            del t_map
+        except Exception as e:                              # noqa: BLE001  keep the headline figure: the cloud is generated locally
+            comm["broadcast_map_error"] = "%s: %s" % (type(e).__name__, e)
+            if map_xy is None:
+                map_xy = synth.make_map(cfg["n_map"], cfg["half"])
     truths = None
     if c5:
         # one scan, broadcast from rank 0; seeds sharded: rank r takes every 8th seed of the 4096-seed lattice
@@ -248,8 +276,12 @@ def main():
     torch.cuda.synchronize()
 
     nst = args.steps + args.warmup
-    ev_a = [torch.cuda.Event(enable_timing=args.time_builds) for _ in range(2 * nst)]
-    ev_m = [torch.cuda.Event(enable_timing=args.time_builds) for _ in range(2 * nst)]
+    side_legs = world == 1 and not args.no_single_scan and not c5      # steady-state and moving-map legs behind the timed region
+    n_extra = (max(0, args.steady_steps) + max(0, args.moving_steps)) if side_legs else 0
+    ev_a = [torch.cuda.Event(enable_timing=args.time_builds) for _ in range(2 * (nst + n_extra))]
+    ev_m = [torch.cuda.Event(enable_timing=args.time_builds) for _ in range(2 * (nst + n_extra))]
+    stats = {"rebuilt_steps": 0}
+    cloud_of = [lambda i: d_map]                           # the cloud step i rebuilds its map from (the moving-map leg swaps this)
     best_log = []
     tp_off = capi.RESULT_DTYPE.fields["trans_prob"][1]
     seed_index = (rank + SEED_SHARDS * torch.arange(B, dtype=torch.int64)).to(comm_dev) if c5 else None
@@ -268,27 +300,12 @@ def main():
             mctx[c].wait_launch(n_launched[c] - 1 - launch_no[j], stream.cuda_stream)
 
 
-    def step(i):
+    def launch(i):
+        """a3-a9 for the whole batch of step i: one launch behind this step's build (the library makes the match stream
+        wait for the build of the map it is given: no second wait here -- every wait is a packet between two kernels),
+        then the collective of the step."""
         gm = gmaps[i % nbuf]
         st, cx = streams[i % args.inflight], mctx[i % args.inflight]
-        # a2: rebuild the voxel grid of this step in place, as soon as the matches of step i - nbuf (the last
-        # readers of this grid) are done
-        if i >= nbuf:
-            wait_step_done(bstream, i - nbuf)
-        if args.time_builds:
-            ev_m[2 * i].record(bstream)
-        # two-phase rebuild (ndt_map_rebuild_begin / _end): the build is queued with the voxel grid of the map's last
-        # build and the host goes on -- it collects the verdict on that grid one step later, so the GPU never waits for
-        # the host's wake-up from the bounding-box read-back (a plain rebuild blocks right here in every step)
-        if open_build:
-            stale = open_build.pop().rebuild_end()
-            assert not stale, "the map's bounding box moved: the matches queued on the speculative grid would have to be repeated"
-        gm.rebuild_begin(d_map.data_ptr(), len(map_xy), 8)
-        open_build.append(gm)
-        if args.time_builds:
-            ev_m[2 * i + 1].record(bstream)
-        # a3-a9 for the whole batch: one launch, after this step's build (the library makes the match stream wait
-        # for the build of the map it is given: no second wait here -- every wait is a packet between two kernels)
         out = d_res2[i % nbuf]
         if i >= nbuf and args.inflight > 1:
             wait_step_done(st, i - nbuf)               # the previous writer of this result buffer: another stream when inflight > 1
@@ -322,16 +339,56 @@ def main():
                     comm["argmax_error"] = "%s: %s" % (type(e).__name__, e)
                 ev_done[i % nbuf].record(side)
 
+    dbg_t = []                                             # NDT_BENCH_DEBUG: host time of the calls of a step
+
+    def settle_build():
+        """Collect the verdict on the grid the open rebuild was queued with.  NDT_REBUILT: the cloud's voxel bounding box
+        had moved (the common case for the reference's sliding local map, src/PointCloudMap.cpp:119-131) -- the library has
+        queued the build again with the right grid, and the matches of that step, which ran on the stale one, are queued
+        again here: the step costs one more build and one more launch."""
+        if open_build:
+            gm, j = open_build.pop()
+            ta = time.perf_counter()
+            stale = gm.rebuild_end()
+            dbg_t.append(("end", time.perf_counter() - ta))
+            if stale:
+                stats["rebuilt_steps"] += 1
+                ta = time.perf_counter()
+                launch(j)
+                dbg_t.append(("relaunch", time.perf_counter() - ta))
+
+    def step(i):
+        gm = gmaps[i % nbuf]
+        # a2: rebuild the voxel grid of this step in place, as soon as the matches of step i - nbuf (the last
+        # readers of this grid) are done
+        if i >= nbuf:
+            wait_step_done(bstream, i - nbuf)
+        if args.time_builds:
+            ev_m[2 * i].record(bstream)
+        # two-phase rebuild (ndt_map_rebuild_begin / _end): the build is queued with the voxel grid of the map's last
+        # build and the host goes on -- it collects the verdict on that grid one step later, so the GPU never waits for
+        # the host's wake-up from the bounding-box read-back (a plain rebuild blocks right here in every step)
+        settle_build()
+        ta = time.perf_counter()
+        gm.rebuild_begin(cloud_of[0](i).data_ptr(), len(map_xy), 8)
+        dbg_t.append(("begin", time.perf_counter() - ta))
+        open_build.append((gm, i))
+        if args.time_builds:
+            ev_m[2 * i + 1].record(bstream)
+        ta = time.perf_counter()
+        launch(i)
+        dbg_t.append(("launch", time.perf_counter() - ta))
+
     for i in range(args.warmup):
         step(i)
     fence()
     t0 = time.perf_counter()
     for i in range(args.warmup, nst):
         step(i)
-    if open_build:                                         # the verdict on the last step's grid belongs to the timed region
-        assert not open_build.pop().rebuild_end()
+    settle_build()                                         # the verdict on the last step's grid belongs to the timed region
     fence()
     elapsed = time.perf_counter() - t0
+    rebuilt_timed = stats["rebuilt_steps"]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -366,6 +423,68 @@ def main():
         per_rank = {"kernel_ms": [float(t[0]) for t in allr], "kernel_ms_max": [float(t[1]) for t in allr],
                     "evals": [float(t[2]) for t in allr]}
 
+    # ---- side legs behind the timed region (N = 1): the same pipelined step, (i) for >= 200 more steps -- the driver's
+    # 20 timed steps are 10 ms, about the length of the GPU's clock ramp -- and (ii) with a local map whose voxel bounding
+    # box moves every k-th step, the path the reference takes (src/PointCloudMap.cpp:119-131): the speculative grid of the
+    # two-phase rebuild is then wrong, the library builds again and the step's matches are queued again (settle_build).
+    legs = {}
+    nxt = nst
+    if side_legs and args.steady_steps > 0:
+        fence()
+        t0 = time.perf_counter()
+        for i in range(nxt, nxt + args.steady_steps):
+            step(i)
+        settle_build()
+        fence()
+        el = time.perf_counter() - t0
+        nxt += args.steady_steps
+        legs["steady_state"] = {"steps": args.steady_steps, "ms_per_step": 1e3 * el / args.steady_steps,
+                                "value": B * args.steady_steps / el,
+                                "note": "the timed loop continued for this many more steps (clock ramped, queues warm)"}
+    if side_legs and args.moving_steps > 0:
+        # cloud B = the cloud with ONE point moved a voxel beyond the bounding box's lower corner: the grid's origin moves by a
+        # voxel in x and y (every voxel index changes), the matches stay what they were
+        mv = map_xy.copy()
+        mv[0] = map_xy.min(axis=0) - np.float32(cfg["resolution"])
+        d_map_b = torch.from_numpy(mv).to(dev)
+        clouds = [d_map, d_map_b]
+        base_i, k_mv = nxt, max(1, args.moving_every)
+        cloud_of[0] = lambda i: clouds[((i - base_i) // k_mv) % 2]
+        before = stats["rebuilt_steps"]
+        fence()
+        t0 = time.perf_counter()
+        for i in range(nxt, nxt + args.moving_steps):
+            if os.environ.get("NDT_BENCH_DEBUG"):
+                tq = time.perf_counter(); rb = stats["rebuilt_steps"]
+                step(i)
+                tq1 = time.perf_counter()
+                if os.environ.get("NDT_BENCH_DEBUG") == "2":
+                    torch.cuda.synchronize()
+                print("moving step %d: host %.3f ms, +sync %.3f ms, rebuilt %d" % (i - nxt, (tq1 - tq) * 1e3, (time.perf_counter() - tq) * 1e3, stats["rebuilt_steps"] - rb),
+                      " ".join("%s %.3f" % (k, v * 1e3) for k, v in dbg_t[-5:]), file=sys.stderr)
+                del dbg_t[:]
+                continue
+            step(i)
+        settle_build()
+        fence()
+        el = time.perf_counter() - t0
+        last_i = nxt + args.moving_steps - 1
+        nxt += args.moving_steps
+        got_mv = d_res2[last_i % nbuf].cpu().numpy().tobytes()
+        fresh = capi.Map(ctx, params=prm, dev_ptr=cloud_of[0](last_i).data_ptr(), n=len(map_xy), stride=8)   # a build from scratch
+        chk = torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+        fresh.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, total_points, d_init.data_ptr(), chk.data_ptr(),
+                              shared_scan=c5, stream=stream.cuda_stream)
+        torch.cuda.synchronize()
+        legs["moving_map"] = {"steps": args.moving_steps, "box_moves_every": k_mv,
+                              "rebuilt_steps": stats["rebuilt_steps"] - before,
+                              "ms_per_step_moving": 1e3 * el / args.moving_steps, "value_moving": B * args.moving_steps / el,
+                              "identical_to_a_fresh_build": bool(chk.cpu().numpy().tobytes() == got_mv),
+                              "note": "two map buffers, each speculating on the grid of ITS last build: a move of the box costs "
+                                      "one extra build + one repeated launch on each of them"}
+        fresh.close()
+        cloud_of[0] = lambda i: d_map
+
     out = None
     if rank == 0:
         traffic, traffic_src = measured_traffic()
@@ -377,6 +496,13 @@ def main():
                 "8 x 512 = 4096-seed lattice)" % (B, n_scan, cfg["n_map"], world)) if c5 else (
                 "BASELINE configs[2]: batch of %d scans x %d pts vs shared %d-pt map, 0.5 m voxels, per GPU (configs[3] sharding "
                 "at N>1)" % (B, n_scan, cfg["n_map"]))
+        v_cells = int(gmaps[0].info().n_cells)              # voxels of the search set (>= min_pts points)
+        mb_bytes = len(map_xy) * 8.0 + v_cells * 24.0
+        mb_ms = float(np.median(solo_build_ms))
+        map_build_roofline = {"kernels": "the chain of ndt_map_build_dev (DESIGN.md 4.1), alone on the GPU", "ms": mb_ms,
+                              "map_points": int(len(map_xy)), "voxels": v_cells, "algorithmic_bytes_per_build": mb_bytes,
+                              "achieved_GBps": mb_bytes / (mb_ms * 1e-3) / 1e9, "frac": mb_bytes / (mb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "note": "SURVEY 8d: M x 8 B read + V x 24 B written"}
         out = {
             "metric": "scan-matches/sec (10k-pt scan vs 1M-pt NDT map)" if not c5 else "scan-matches/sec (seed poses of one 10k-pt scan vs 5M-pt NDT map)",
             "value": world * B * args.steps / elapsed,
@@ -388,9 +514,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": what + "; map rebuilt every step from the same cloud (the rebuild of step i+1 overlaps the end of step i's "
-                                   "matches; the cloud's voxel bounding box never moves, so the grid the two-phase rebuild queues ahead "
-                                   "with is always the right one -- a moved box costs one more build, `reference_faithful` rebuilds "
-                                   "synchronously); %d match launch(es) in flight; parameter preset PCL 1.10" % args.inflight,
+                                   "matches; the cloud's voxel bounding box never moves in the timed region, so the grid the two-phase "
+                                   "rebuild queues ahead with is always the right one -- `moving_map` times a box that moves, "
+                                   "`reference_faithful` rebuilds synchronously); %d match launch(es) in flight; parameter preset PCL 1.10" % args.inflight,
                        "matches_per_gpu": B, "scans_per_gpu": B if not c5 else 1, "scan_points": n_scan, "map_points": cfg["n_map"],
                        "resolution": cfg["resolution"], "inflight": args.inflight, "workgroups": args.workgroups, "max_helpers": args.max_helpers,
                        "parallelism": ("seed-shards x%d, scan broadcast, arg-max of scores" % world) if c5 else
@@ -406,14 +532,19 @@ def main():
                          "launch_interval_ms": float(np.mean(kern_ms)) if kern_ms else None,
                          "fitness": {"kernels": "fitness_points_kernel + fitness_far_kernel + fitness_reduce_kernel" if c5 else "fitness_points_kernel + fitness_reduce_kernel", "ms": fit_ms,
                                      "algorithmic_bytes_per_launch": fit_bytes,
-                                     "achieved_GBps": fit_bytes / (fit_ms * 1e-3) / 1e9 if fit_ms > 0 else None},
+                                     "achieved_GBps": fit_bytes / (fit_ms * 1e-3) / 1e9 if fit_ms > 0 else None,
+                                     "frac": fit_bytes / (fit_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if fit_ms > 0 else None,
+                                     "note": "SURVEY 8d: N x 16 B per match (the point + its nearest map point)"},
+                         "map_build": map_build_roofline,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "mean_evals": float(res["evals"].mean()), "max_evals": int(res["evals"].max()),
                          "mean_kbar": float(res["kbar"].mean())},
             "map_build_ms": float(np.median(solo_build_ms)), "map_build_in_step_ms": float(np.mean(map_ms)) if map_ms else None,
             "converged": int(res["converged"].sum()),
             "accepted": int(accepted.sum()), "accepted_frac": float(accepted.mean()),
+            "rebuilt_steps": rebuilt_timed,
         }
+        out.update(legs)
         # fp64 arithmetic rate next to the byte rate (SURVEY 8d asks for it so that the HBM figure is not misread):
         # per (point, voxel) pair ~ 100 flops, per point-evaluation ~ 60 (transform, voxel index, 9 radius tests)
         pe = float(np.sum(res["evals"].astype(np.float64) * n_scan))

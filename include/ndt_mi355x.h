@@ -148,8 +148,9 @@ int ndt_map_build_dev(ndt_ctx *ctx, const float *xy_dev, size_t n, size_t stride
  * bounding box of the new cloud and, ahead of its read-back, the whole build with the voxel grid of the map's previous
  * build, and returns; launches queued behind it see that build.  _end waits for the bounding box: NDT_OK if the grid
  * was the right one (a SLAM local map keeps its voxel bounding box for many scans, src/PointCloudMap.cpp:119-131),
- * NDT_REBUILT if it was not -- the build has been queued again, and whatever was queued between _begin and _end ran on
- * a stale grid and has to be queued again by the caller.  One _begin may be open per context (other builds on that
+ * NDT_REBUILT if it was not -- the build has been queued again (behind the launches of ANY context that read the map
+ * since _begin: it rewrites the tables they read), and whatever was queued between _begin and _end ran on a stale grid
+ * and has to be queued again by the caller.  One _begin may be open per context (other builds on that
  * context fail with NDT_E_ARG until _end); xy_dev must stay as it is until _end has returned.  The map must have been
  * built before at the same resolution. */
 #define NDT_REBUILT 1
@@ -193,7 +194,11 @@ int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_
  * matches are independent given the read-only map, so a batch that starts on the host needs no xGMI
  * traffic at all.  `shared_scan`: the one scan goes to every device, the B seed poses are sharded.  Synchronous; same
  * results as ndt_align_batch on one device, byte for byte.  (One process per GPU over torch.distributed / RCCL is the
- * other form: ndt_slam_amd/shard.py.)  Replaces a loop of src/ScanMatcher.cpp:40,45 over independent scans. */
+ * other form: ndt_slam_amd/shard.py.)  Replaces a loop of src/ScanMatcher.cpp:40,45 over independent scans.
+ * Errors: every shard is attempted; the call returns the FIRST shard's error code.  The records of a shard that failed
+ * are all overwritten -- zeroed, `status` = that shard's error, `converged` = 0, `fitness` = DBL_MAX (the shim's 1e7
+ * case, src/PoseEstimator.cpp:44-46) -- and the records of the shards that succeeded are complete, so `status` tells
+ * per record what can be used (tests/test_gpu_parity.py::test_sharded_batch_marks_every_record_of_a_failed_shard). */
 int ndt_align_batch_sharded(ndt_ctx *const *ctxs, const ndt_map *const *maps, int n_shards, const float *scans_xy_host,
                             const uint64_t *offsets, int B, int shared_scan, const double *inits_xyyaw,
                             ndt_result *results);

@@ -50,6 +50,7 @@ RESULT_DTYPE = np.dtype([
     ("flags", "i4"), ("kbar", "f8")], align=True)
 RESULT_BYTES = RESULT_DTYPE.itemsize
 FLAG_WINDOW_SPILL, FLAG_REGION_CLIPPED, FLAG_UNSORTED = 1, 2, 4      # ndt_result.flags
+NDT_OK, NDT_E_ARG, NDT_E_HIP, NDT_E_NO_DEVICE, NDT_E_GRID, NDT_E_NOMEM = 0, -1, -2, -3, -4, -5    # ndt_status
 OPT_MAX_HELPERS, OPT_WORKGROUPS = 1, 2                                # ndt_ctx_set_option
 
 EXPORTS = [
@@ -136,8 +137,10 @@ def default_params(preset="default", **kw):
     return p
 
 
-def align_batch_sharded(maps, scans, offsets, inits, shared_scan=False):
-    """ndt_align_batch_sharded: `maps` = one Map per device (each with its own Context), the batch on the host."""
+def align_batch_sharded(maps, scans, offsets, inits, shared_scan=False, partial=False):
+    """ndt_align_batch_sharded: `maps` = one Map per device (each with its own Context), the batch on the host.
+    `partial`: return (rc, records) instead of raising when a shard failed -- every record of a failed shard carries
+    that shard's error in `status`, the others are complete."""
     scans = _f32c(scans)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     inits = np.ascontiguousarray(inits, dtype=np.float64).reshape(-1, 3)
@@ -148,6 +151,8 @@ def align_batch_sharded(maps, scans, offsets, inits, shared_scan=False):
     mp = (C.c_void_p * n)(*[m.h for m in maps])
     rc = lib().ndt_align_batch_sharded(cx, mp, n, scans.ctypes.data, offsets.ctypes.data, B, int(shared_scan),
                                        inits.ctypes.data, res.ctypes.data)
+    if partial:
+        return rc, res
     if rc:
         raise NdtError("ndt_align_batch_sharded -> %d: %s" % (rc, lib().ndt_last_error(None).decode()))
     return res

@@ -26,6 +26,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <set>
 #include <utility>
 #include <vector>
 
@@ -118,9 +119,16 @@ struct ndt_map {
   const float *pend_xy = nullptr; size_t pend_stride = 0;
   GridDims grid; bool have_grid = false;      // voxel grid of the last build (queued ahead of the next one's bounding box)
   void *d_xy_stage = nullptr; size_t d_xy_cap = 0;
+  // Launches that read this map since its last build_begin, one entry per reading context: (context, number of that launch
+  // in the context's event ring).  A build that has to be queued AGAIN (build_end: the speculative grid was wrong) rewrites
+  // the tables those launches read -- on another stream when the caller builds and matches on different contexts -- and
+  // must wait for them first (round 4: a fitness kernel walking bucket offsets that were being rebuilt ran 236 ms).
+  std::vector<std::pair<ndt_ctx *, unsigned long long>> readers;
 };
 
 namespace {
+
+std::set<ndt_ctx *> g_live_ctx;                // contexts that exist (a map may outlive a context that only READ it)
 
 int fail(ndt_ctx *ctx, int code, const std::string &msg) {
   g_last_error = msg;
@@ -275,6 +283,12 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
     hipExtLaunchKernelGGL(fitness_reduce_kernel, dim3(std::min(B, 4 * ctx->num_cus)), dim3(kFitBlock), 0, st, nullptr, evr[2], 0,
                           offsets, B, shared_scan, (const float *)fit, out, (uint4 *)ws, (unsigned)(zero_bytes / 16));
   }
+  {                                           // this launch reads the map: a re-queued build must wait for it (ndt_map::readers)
+    auto &rd = const_cast<ndt_map *>(map)->readers;
+    bool found = false;
+    for (auto &r : rd) if (r.first == ctx) { r.second = ctx->launches; found = true; }
+    if (!found) rd.emplace_back(ctx, ctx->launches);
+  }
   ctx->launches++;
   HIP_TRY(ctx, hipGetLastError());
   ctx->ws_clean = zero_bytes;
@@ -367,6 +381,7 @@ int ndt_ctx_create(int device, ndt_ctx **out) {
   if (!c) return NDT_E_NOMEM;
   const int rc = ctx_init(c, device);
   if (rc) { ndt_ctx_destroy(c); return rc; }      // (the error text stays in ndt_last_error(NULL))
+  g_live_ctx.insert(c);
   *out = c;
   return NDT_OK;
 }
@@ -386,6 +401,7 @@ int ndt_ctx_set_option(ndt_ctx *c, int option, long long value) {
 
 int ndt_ctx_destroy(ndt_ctx *c) {
   if (!c) return NDT_E_ARG;
+  g_live_ctx.erase(c);
   hipError_t e;
   e = hipSetDevice(c->device);
   if (c->stream) e = hipStreamSynchronize(c->stream);
@@ -579,6 +595,7 @@ static int build_begin(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   hipStream_t st = ctx->stream;
   m->prm = *prm; m->n = n; m->info_valid = false;
   m->pend_xy = xy; m->pend_stride = stride; m->pend_queued = false;
+  m->readers.clear();                          // whoever read the previous build is the caller's to wait for (stream order / ndt_ctx_wait_launch)
   HIP_TRY(ctx, hipEventRecord(ctx->evm0, st));
   // The bounding box (and the reset of the centroid grid, queue_build) run on a side stream beside the bucketing
   // chain -- a dozen dependent kernels whose launch latencies add up -- and are joined in front of the statistics.
@@ -621,6 +638,16 @@ static int build_end(ndt_ctx *ctx, ndt_map *m) {
                     G.div_x == m->grid.div_x && G.div_y == m->grid.div_y;
   int redone = 0;
   if (!same) {
+    if (m->pend_queued) {
+      // the launches queued since build_begin read the speculative build's tables: the build that replaces them waits
+      // for the last of them on every context that issued any (the event on that launch's last kernel)
+      for (auto &r : m->readers) {
+        ndt_ctx *rc_ = r.first;
+        if (!g_live_ctx.count(rc_) || rc_->launches <= r.second || rc_->launches - 1 - r.second >= (unsigned long long)ndt_ctx::kTimeRing) continue;
+        hipEvent_t *evr = rc_->ev_ring + 3 * (r.second % ndt_ctx::kTimeRing);
+        HIP_TRY(ctx, hipStreamWaitEvent(st, evr[2], 0));
+      }
+    }
     int rc = queue_build(ctx, m, m->pend_xy, m->n, m->pend_stride, prm, G, /*requeue=*/m->pend_queued);
     if (rc) return rc;
     redone = m->pend_queued ? 1 : 0;
@@ -771,13 +798,13 @@ int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, co
   if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
   if (!map || !scans || !offsets || !inits || !out || B <= 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: bad arguments");
   if (map->ctx->device != ctx->device) return fail(ctx, NDT_E_ARG, "ndt_align_batch: the map was built on another device");
+  if (total_points == 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: total_points = 0");   // (before the scratch bracket opens)
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   // the map build may still be running on the stream of the context that built the map
   if (st != map->ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(st, map->ctx->evm1, 0));
   int rc;
   if ((rc = scratch_begin(ctx, st))) return rc;
-  if (total_points == 0) return fail(ctx, NDT_E_ARG, "ndt_align_batch: total_points = 0");
   if ((rc = launch_align(ctx, map, st, scans, (const unsigned long long *)offsets, B, shared_scan, total_points, inits,
                          out, nullptr, 0, nullptr, nullptr)))
     return rc;
@@ -927,7 +954,7 @@ int ndt_align_batch_sharded(ndt_ctx *const *ctxs, const ndt_map *const *maps, in
   // contiguous, balanced shards: the first B % n_shards get one match more (ndt_slam_amd/shard.py: shard_bounds)
   const int base = B / n_shards, extra = B % n_shards;
   std::vector<std::vector<uint64_t>> offs((size_t)n_shards);
-  std::vector<int> queued((size_t)n_shards, 0);
+  std::vector<int> queued((size_t)n_shards, 0), shard_rc((size_t)n_shards, NDT_OK);
   int rc_first = NDT_OK;
   for (int r = 0; r < n_shards; ++r) {            // queue every shard on its own device: uploads, launch, read-back
     const int lo = r * base + std::min(r, extra), n = base + (r < extra ? 1 : 0);
@@ -941,12 +968,25 @@ int ndt_align_batch_sharded(ndt_ctx *const *ctxs, const ndt_map *const *maps, in
       rc = align_host_queue(ctxs[r], maps[r], scans + 2 * (size_t)offsets[lo], 8, offs[r].data(), n, 0, inits + 3 * (size_t)lo,
                             out + lo, nullptr, 0, nullptr);
     }
-    if (rc) { if (!rc_first) rc_first = rc; } else queued[r] = 1;
+    if (rc) { shard_rc[r] = rc; if (!rc_first) rc_first = rc; } else queued[r] = 1;
   }
   for (int r = 0; r < n_shards; ++r) {            // ... then wait for all of them
     if (!queued[r]) continue;
     const int rc = align_host_finish(ctxs[r]);
-    if (rc && !rc_first) rc_first = rc;
+    if (rc) { shard_rc[r] = rc; if (!rc_first) rc_first = rc; }
+  }
+  // A failed shard must not leave its part of `results` as the caller handed it over: every record of it says so
+  // (status = the shard's error, not converged, fitness DBL_MAX -- what a caller maps to the reference's 1e7 sentinel,
+  // src/PoseEstimator.cpp:44-46); the other shards' records are complete and valid.  The call returns the first error.
+  for (int r = 0; r < n_shards; ++r) {
+    if (!shard_rc[r]) continue;
+    const int lo = r * base + std::min(r, extra), n = base + (r < extra ? 1 : 0);
+    for (int k = 0; k < n; ++k) {
+      ndt_result z;
+      memset(&z, 0, sizeof(z));
+      z.status = shard_rc[r]; z.fitness = DBL_MAX;
+      out[lo + k] = z;
+    }
   }
   return rc_first;
 }

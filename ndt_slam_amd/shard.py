@@ -67,6 +67,36 @@ def scatter_batch(scans, offsets, inits, src=0, device="cpu"):
     return t_sc, t_of, t_in
 
 
+def broadcast_map(points, src=0, device="cpu", chunk_bytes=8 << 20):
+    """The target cloud lives on ONE rank (the reference's local map is assembled by one PointCloudMap,
+    src/PointCloudMap.cpp:119-134, and handed over at src/ScanMatcher.cpp:40): rank `src` passes it as an [n, 2] float32
+    numpy array or tensor (None elsewhere); every rank returns it as a float32 tensor [n, 2] on `device`, ready for
+    ndt_map_build_dev by data_ptr() -- each rank then builds its own cell table from it ("build
+    redundantly from a broadcast of raw points": 8 MB for the 1M-point map, 40 MB for configs[4]'s).  One broadcast of
+    the point count, then the points in pieces of at most `chunk_bytes` (collectives of bounded size: the 40 MB cloud goes
+    as five 8 MB broadcasts; RCCL over xGMI on the GPU box, gloo in the CPU tests)."""
+    rank = dist.get_rank()
+    device = torch.device(device)
+    if rank == src:
+        t = points if torch.is_tensor(points) else torch.from_numpy(np.ascontiguousarray(points, dtype=np.float32))
+        if t.dim() != 2 or t.shape[1] != 2 or t.dtype != torch.float32:
+            raise ValueError("expected an [n, 2] float32 cloud")
+        t = t.to(device).contiguous()
+        n = torch.tensor([t.shape[0]], dtype=torch.int64, device=device)
+    else:
+        t = None
+        n = torch.zeros(1, dtype=torch.int64, device=device)
+    dist.broadcast(n, src=src)
+    count = int(n.item())
+    if t is None:
+        t = torch.empty((count, 2), dtype=torch.float32, device=device)
+    flat = t.view(-1)
+    step = max(2, (int(chunk_bytes) // 8) * 2)               # whole points per piece
+    for a in range(0, flat.numel(), step):
+        dist.broadcast(flat[a:a + step], src=src)
+    return t
+
+
 _GATHER_OK = True
 
 

@@ -33,6 +33,18 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     assert d["value"] > 100 * c["value"]
     assert 0 < d["map_build_ms"] < d["ms_per_step"]
     assert d["parity"]["max_dpos_m"] <= 1e-4 and d["parity"]["max_dyaw_rad"] <= 1e-4
+    # the two genuinely HBM-bound kernel groups of SURVEY 8d carry their own roofline figures
+    mb, ft = r["map_build"], r["fitness"]
+    assert abs(mb["algorithmic_bytes_per_build"] - (8.0 * mb["map_points"] + 24.0 * mb["voxels"])) < 1 and 0 < mb["frac"] < 1
+    assert abs(mb["frac"] - mb["achieved_GBps"] / r["peak"]) < 1e-12 and 0 < ft["frac"] < 1
+    # the path the reference takes: a local map whose voxel bounding box moves.  The timed region never moves it ...
+    assert d["rebuilt_steps"] == 0
+    # ... the side leg does: every move is found (two map buffers: two stale grids per move), the step is repeated, and the
+    # records are those of a build from scratch
+    mv = d["moving_map"]
+    assert mv["steps"] == 48 and mv["box_moves_every"] == 8 and mv["rebuilt_steps"] == 2 * (48 // 8 - 1)
+    assert mv["identical_to_a_fresh_build"] is True and 0 < mv["ms_per_step_moving"] < 3 * d["ms_per_step"]
+    assert d["steady_state"]["steps"] == 200 and d["steady_state"]["value"] > 0
 
 
 def test_two_rank_path_walks_through_on_one_gpu():
@@ -51,6 +63,8 @@ def test_two_rank_path_walks_through_on_one_gpu():
     assert d["config"]["scans_per_gpu"] == 256 and "x2" in d["config"]["parallelism"]
     assert "scatter from rank 0" in d["config"]["parallelism"] and d["comm"]["scatter_ms"] > 0
     assert len(d["per_rank"]["kernel_ms"]) == 2 and min(d["per_rank"]["kernel_ms"]) > 0
+    assert d["comm"]["broadcast_map_ms"] > 0 and d["comm"]["broadcast_map_bytes"] == 8_000_000      # the target cloud's fan-out
+    assert d["comm"]["broadcast_map_identical_on_every_rank"] is True and "broadcast_map_error" not in d["comm"]
     assert "cpu_baseline" not in d                     # the CPU leg runs at N = 1 only
     mh = d["multi_hypothesis"]                         # the configs[4] leg of the default run, both ranks
     assert "error" not in mh, mh
@@ -90,12 +104,13 @@ def test_four_rank_path_with_the_ranks_contending_for_one_gpu():
     env = dict(os.environ, NDT_BENCH_REHEARSAL="1", MASTER_ADDR="127.0.0.1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
                           "--master-addr", "127.0.0.1", "--master-port", "29523", os.path.join(ROOT, "bench.py"),
-                          "--gpus", "4", "--steps", "4", "--warmup", "2", "--no-single-scan", "--no-cpu-baseline"],
+                          "--gpus", "4", "--steps", "4", "--warmup", "2", "--no-single-scan", "--no-cpu-baseline", "--map-from-rank0"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 4 and d["value"] > 0 and len(d["per_rank"]["kernel_ms"]) == 4
     assert "scatter_error" not in d["comm"] and "gather_error" not in d["comm"]
+    assert "broadcast_map_error" not in d["comm"] and d["comm"]["broadcast_map_ms"] > 0     # --map-from-rank0: ranks 1-3 matched on the copy
     assert max(d["per_rank"]["kernel_ms_max"]) < 50.0              # ms: no launch waited for another process's kernels to end
     assert d["converged"] == 256 and d["accepted"] == 256
 
@@ -113,6 +128,9 @@ off = np.array([0, 5, 5, 12], np.uint64); scans = rng.standard_normal((12, 2)).a
 sc, of, ini = shard.scatter_batch(scans, off, inits, src=0, device=dev)
 assert sc.is_cuda and sc.cpu().numpy().tobytes() == scans.tobytes() and of.cpu().tolist() == [0, 5, 5, 12]
 pay = torch.arange(2003, dtype=torch.float64, device=dev); dist.broadcast(pay, src=0)
+cloud = rng.standard_normal((5000, 2)).astype(np.float32)
+mt = shard.broadcast_map(cloud, src=0, device=dev, chunk_bytes=16384)              # int64 count + chunked float32 broadcasts
+assert mt.is_cuda and mt.cpu().numpy().tobytes() == cloud.tobytes()
 got = shard.gather_results(torch.arange(216, dtype=torch.uint8, device=dev), dst=0)
 assert len(got) == 1 and got[0].cpu().tolist() == list(range(216))
 t, i = shard.best_hypothesis_t(torch.tensor([0.5, 2.5, 2.5], dtype=torch.float64, device=dev), torch.tensor([8, 16, 24], dtype=torch.int64, device=dev))

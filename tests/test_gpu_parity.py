@@ -155,6 +155,56 @@ def test_rebuild_with_a_moved_bounding_box_leaves_no_phantom_voxels(gpu, oracle,
         gm.close(); fresh.close()
 
 
+def test_requeued_build_waits_for_the_launches_that_read_the_stale_tables(gpu):
+    """Builds and matches on DIFFERENT contexts / streams (the bench's pipeline): rebuild_begin queues the build with the
+    old grid, a batch is launched on the other context, rebuild_end finds the box moved and queues the build again -- which
+    rewrites the bucket offsets and points the launch's fitness kernel is still reading unless it waits for that launch.
+    (Round 4, found by the bench's moving-map leg: the search walked half-rebuilt offsets for 236 ms.)  The stale launch
+    must finish in its usual time, and the launch queued again must equal a build from scratch byte for byte."""
+    import time
+    import torch
+    capi = gpu[0]
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C3"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    B = 64
+    scans, off, truths, inits = sf.batch(0, B)
+    mv = m.copy(); mv[0] = m.min(axis=0) - np.float32(cfg["resolution"])          # the box's lower corner moves by a voxel
+    dev = torch.device("cuda", 0)
+    d_a, d_b = torch.from_numpy(m).to(dev), torch.from_numpy(mv).to(dev)
+    d_s = torch.from_numpy(scans).to(dev); d_o = torch.from_numpy(off.astype(np.int64)).to(dev); d_i = torch.from_numpy(inits).to(dev)
+    d_r = torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+    bstream, mstream = torch.cuda.Stream(device=dev, priority=-1), torch.cuda.Stream(device=dev)
+    bctx, mctx = capi.Context(0), capi.Context(0)
+    bctx.set_stream(bstream.cuda_stream); mctx.set_stream(mstream.cuda_stream)
+    prm = capi.default_params(resolution=cfg["resolution"])
+    gm = capi.Map(bctx, params=prm, dev_ptr=d_a.data_ptr(), n=len(m), stride=8)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for rep in range(6):
+        cloud = d_b if rep % 2 == 0 else d_a                                         # the box moves on every rebuild
+        t0 = time.perf_counter()
+        gm.rebuild_begin(cloud.data_ptr(), len(m), 8)
+        gm.align_batch_dev(d_s.data_ptr(), d_o.data_ptr(), B, len(scans), d_i.data_ptr(), d_r.data_ptr(),
+                           stream=mstream.cuda_stream, ctx=mctx)
+        assert gm.rebuild_end() is True
+        gm.align_batch_dev(d_s.data_ptr(), d_o.data_ptr(), B, len(scans), d_i.data_ptr(), d_r.data_ptr(),
+                           stream=mstream.cuda_stream, ctx=mctx)
+        torch.cuda.synchronize()
+        worst = max(worst, time.perf_counter() - t0)
+        got = np.frombuffer(d_r.cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
+        assert np.all(got["status"] == 0)
+        fresh = capi.Map(mctx, params=prm, dev_ptr=cloud.data_ptr(), n=len(m), stride=8)
+        d_f = torch.zeros_like(d_r)
+        fresh.align_batch_dev(d_s.data_ptr(), d_o.data_ptr(), B, len(scans), d_i.data_ptr(), d_f.data_ptr(), stream=mstream.cuda_stream)
+        torch.cuda.synchronize()
+        assert d_f.cpu().numpy().tobytes() == got.tobytes(), rep
+        fresh.close()
+    assert worst < 0.02, worst                                                     # two builds + two launches of 64 matches: ~1 ms
+    gm.close(); bctx.close(); mctx.close()
+
+
 def test_map_destroy_closes_an_open_rebuild(gpu, c1_world):
     """ndt_map_destroy on a map with an open ndt_map_rebuild_begin: the context must be usable afterwards."""
     import torch
@@ -506,6 +556,36 @@ def test_sharded_batch_from_one_process(gpu, c1_world):
     assert got_s.tobytes() == one_s.tobytes()
     with pytest.raises(capi.NdtError):
         capi.align_batch_sharded(maps[:2], scans, off, inits[:0])
+    for mp in maps:
+        mp.close()
+    for c in ctxs:
+        c.close()
+
+
+def test_sharded_batch_marks_every_record_of_a_failed_shard(gpu, c1_world):
+    """One shard fails on purpose (all of its scans are empty: NDT_E_ARG when it is queued): the call returns that error,
+    every record of the failed shard says so (status, not converged, fitness DBL_MAX) -- even though the caller's buffer held
+    plausible-looking records before -- and the other shards' records equal a plain launch byte for byte."""
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    prm = capi.default_params(resolution=cfg["resolution"])
+    scans, off, truths, inits = sf.batch(0, 6)
+    lens = np.diff(off.astype(np.int64))
+    keep = np.ones(len(scans), bool); keep[int(off[2]):int(off[4])] = False     # scans 2 and 3 = shard 1 of 3: empty
+    lens[2] = lens[3] = 0
+    scans_e = scans[keep]; off_e = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    ctxs = [capi.Context(0) for _ in range(3)]
+    maps = [capi.Map(c, m, prm) for c in ctxs]
+    good = maps[0].align_batch(scans, off, inits)
+    rc, got = capi.align_batch_sharded(maps, scans_e, off_e, inits, partial=True)
+    assert rc == capi.NDT_E_ARG
+    for b in (0, 1, 4, 5):
+        assert got[b].tobytes() == good[b].tobytes(), b
+    for b in (2, 3):
+        assert int(got[b]["status"]) == capi.NDT_E_ARG and int(got[b]["converged"]) == 0
+        assert got[b]["fitness"] == np.finfo(np.float64).max and not got[b]["pose"].any() and int(got[b]["iters"]) == 0
+    with pytest.raises(capi.NdtError):
+        capi.align_batch_sharded(maps, scans_e, off_e, inits)
     for mp in maps:
         mp.close()
     for c in ctxs:

@@ -1,7 +1,8 @@
 """The N > 1 path on CPU: world_size 2 / 4 / 8 `gloo` processes shard a batch, match their shards (with the
 CPU oracle standing in for the kernel -- this test is about the scatter / gather bookkeeping) and
 gather the result records; rank 0 must end up with exactly the single-process results.  The batch (7 scans) is
-never divisible by the world size, and with 8 ranks the last shard is EMPTY."""
+never divisible by the world size, and with 8 ranks the last shard is EMPTY.  The target cloud exists on rank 0 only and
+reaches the others through shard.broadcast_map (chunked)."""
 import os
 import socket
 
@@ -34,7 +35,13 @@ def _worker(rank, world, port, outdir):
     from ndt_slam_amd import synth
     from oracle import ndt_oracle as O
     cfg = synth.CONFIGS["C1"]
-    m = synth.make_map(cfg["n_map"], cfg["half"])                # same map on every rank
+    # the target cloud lives on rank 0 only (src/ScanMatcher.cpp:40: one PointCloudMap hands it over); the others get it
+    # through shard.broadcast_map -- in pieces of 4096 bytes here, so that the 40 KB cloud takes ten collectives
+    m0 = synth.make_map(cfg["n_map"], cfg["half"]) if rank == 0 else None
+    mt = shard.broadcast_map(m0, src=0, chunk_bytes=4096)
+    assert isinstance(mt, torch.Tensor) and mt.dtype == torch.float32 and tuple(mt.shape) == (cfg["n_map"], 2)
+    m = mt.numpy()
+    map_ok = m.tobytes() == synth.make_map(cfg["n_map"], cfg["half"]).tobytes()
     om = O.Map(m, O.default_params(resolution=cfg["resolution"]))
     B = 7                                                         # ragged split: 4 + 3
     if rank == 0:
@@ -62,6 +69,9 @@ def _worker(rank, world, port, outdir):
     mine = torch.from_numpy(lat[rank::world].copy())
     t, gi = shard.best_hypothesis_t(mine, rank + world * torch.arange(len(mine), dtype=torch.int64))
     strided_ok = float(t.item()) == 0.9 and int(gi.item()) == 1
+    flags = torch.tensor([1 if map_ok else 0], dtype=torch.int64)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)                 # every rank received the cloud byte for byte
+    strided_ok = strided_ok and int(flags.item()) == 1
     if rank == 0:
         parts = []
         for r in range(world):

@@ -119,6 +119,39 @@ def test_arg_max_ties_empty_shards_and_negative_scores(tmp_path, world):
     assert all(open(os.path.join(str(tmp_path), "ok%d" % r)).read() == "1" for r in range(world))
 
 
+def _bcast_map_worker(rank, world, port, outdir, src, n, chunk):
+    _init(rank, world, port)
+    cloud = np.random.default_rng(11).standard_normal((n, 2)).astype(np.float32)     # every rank can rebuild the truth
+    calls = []
+    real = dist.broadcast
+
+    def counting(t, src=0, **kw):
+        calls.append(t.numel() * t.element_size())
+        return real(t, src=src, **kw)
+    dist.broadcast = counting
+    try:
+        if rank == src and n % 2:                                                # the source may hand a tensor over as well
+            got = shard.broadcast_map(torch.from_numpy(cloud), src=src, chunk_bytes=chunk)
+        else:
+            got = shard.broadcast_map(cloud if rank == src else None, src=src, chunk_bytes=chunk)
+    finally:
+        dist.broadcast = real
+    pieces = calls[1:]                                                           # calls[0]: the point count
+    ok = (got.dtype == torch.float32 and tuple(got.shape) == (n, 2) and got.numpy().tobytes() == cloud.tobytes()
+          and calls[0] == 8 and sum(pieces) == 8 * n and all(b <= max(chunk, 8) and b % 8 == 0 for b in pieces)
+          and len(pieces) == (0 if n == 0 else -(-8 * n // max(8, chunk // 8 * 8))))
+    _verdict(outdir, rank, ok)
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,src,n,chunk", [(2, 0, 5000, 4096), (3, 2, 777, 1000), (4, 1, 0, 4096), (2, 1, 3, 1 << 20)])
+def test_broadcast_map_from_any_rank_in_bounded_pieces(tmp_path, world, src, n, chunk):
+    """shard.broadcast_map: the cloud arrives byte for byte on every rank, from any source rank, in collectives of at
+    most `chunk_bytes` of whole points; an empty cloud is an empty [0, 2] tensor."""
+    mp.spawn(_bcast_map_worker, args=(world, _free_port(), str(tmp_path), src, n, chunk), nprocs=world, join=True)
+    assert all(open(os.path.join(str(tmp_path), "ok%d" % r)).read() == "1" for r in range(world))
+
+
 def _solo_worker(rank, world, port, outdir):
     _init(rank, world, port)
     scans, off, inits = _batch(5)
@@ -127,6 +160,7 @@ def _solo_worker(rank, world, port, outdir):
     got = shard.gather_results(torch.arange(8, dtype=torch.uint8), dst=0)
     ok = ok and len(got) == 1 and bool((got[0] == torch.arange(8, dtype=torch.uint8)).all())
     ok = ok and shard.best_hypothesis(np.array([0.1, 0.7, 0.7]), 10) == (0.7, 11)
+    ok = ok and shard.broadcast_map(scans, src=0).numpy().tobytes() == scans.tobytes()
     _verdict(outdir, rank, ok)
     dist.destroy_process_group()
 
