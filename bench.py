@@ -164,12 +164,13 @@ def main():
             comm["broadcast_map_ms"] = (time.perf_counter() - t0) * 1e3
             comm["broadcast_map_bytes"] = int(t_map.numel() * 4)
             got = t_map.cpu().numpy()
+            # (a collective: EVERY rank takes part -- a rank without a copy of its own has nothing to compare and says "same")
+            same = torch.tensor([1 if (map_xy is None or got.tobytes() == map_xy.tobytes()) else 0], dtype=torch.int64, device=comm_dev)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)
+            if not args.map_from_rank0:
+                comm["broadcast_map_identical_on_every_rank"] = bool(int(same.item()))
             if map_xy is None:
                 map_xy = got
-            else:
-                same = torch.tensor([1 if got.tobytes() == map_xy.tobytes() else 0], dtype=torch.int64, device=comm_dev)
-                dist.all_reduce(same, op=dist.ReduceOp.MIN)
-                comm["broadcast_map_identical_on_every_rank"] = bool(int(same.item()))
             del t_map
         except Exception as e:                              # noqa: BLE001  keep the headline figure: the cloud is generated locally
             comm["broadcast_map_error"] = "%s: %s" % (type(e).__name__, e)

@@ -174,15 +174,17 @@ scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ 
   int v[kScanPer]; int s = 0;
 #pragma unroll
   for (int k = 0; k < kScanPer; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
-  sh[threadIdx.x] = s;
+  // exclusive prefix of the threads' sums over the block: DPP scan inside a wave, the four wave totals through LDS
+  // (round 4; a Hillis-Steele ladder through LDS with two barriers per step took most of this kernel's 11 us)
+  const int incl_w = (int)wave_incl_scan((unsigned)s);
+  __syncthreads();                               // (sh was used above)
+  if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = incl_w;
   __syncthreads();
-  for (int o = 1; o < kScanBlock; o <<= 1) {
-    int t = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-    __syncthreads();
-    sh[threadIdx.x] += t;
-    __syncthreads();
-  }
-  int run = tile_base + sh[threadIdx.x] - s;
+  int before_w = 0;
+#pragma unroll
+  for (int w = 0; w < kScanBlock / 64; ++w) before_w += (w < (int)(threadIdx.x >> 6)) ? sh[w] : 0;
+  const int incl_b = before_w + incl_w;
+  int run = tile_base + incl_b - s;
   unsigned bigmask = 0;
 #pragma unroll
   for (int k = 0; k < kScanPer; ++k) {
@@ -276,24 +278,72 @@ __device__ __forceinline__ void order_small_voxels(unsigned block, const int *__
 }
 
 constexpr int kBigWavesPerBlock = 4, kBigBlocks = 4096, kBigStage = 512;   // LDS staging: point numbers per wave
+constexpr int kBigRuns = 64;                 // runs of consecutive point numbers per voxel the merge handles (else: rank by counting)
 // One launch for both kinds (they do not depend on each other): workgroups [0, small_blocks) take the small voxels,
 // the kBigBlocks behind them the listed big ones.
+//
+// Big voxels (round 4): a voxel's segment of `perm` is a handful of RUNS of consecutive point numbers -- map_scatter_kernel
+// places every wave-run as a block, and a cloud is appended scan by scan, wall by wall (bench map: 2.5 runs per voxel,
+// 99 % of the voxels <= 8) -- in the order their atomics arrived.  Cloud order = the runs sorted by their first number, so
+// an element's place is (lengths of the runs that start before its run) + (its offset in its run): O(n + runs * n / 64)
+// per voxel instead of the n^2 / 64 comparisons of rank counting (n = 25: the typical wall voxel).  A voxel in more than
+// kBigRuns runs (a cloud in random order) keeps rank counting.
 __global__ void __launch_bounds__(256)
 map_order_kernel(const int *__restrict__ start, size_t ng, unsigned small_blocks, const int *__restrict__ big,
                  const int *__restrict__ nbig, int big_cap, const int *__restrict__ perm, const float *__restrict__ xy,
                  size_t stride, float2 *__restrict__ pts) {
   __shared__ int stage[kBigWavesPerBlock][kBigStage];
+  __shared__ int run_first[kBigWavesPerBlock][kBigRuns], run_pos[kBigWavesPerBlock][kBigRuns + 1];
   if (blockIdx.x < small_blocks) { order_small_voxels(blockIdx.x, start, ng, perm, xy, stride, pts); return; }
   const unsigned bblock = blockIdx.x - small_blocks, bblocks = gridDim.x - small_blocks;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const u64 lt = (1ull << lane) - 1ull;
   const int count = min(*nbig, big_cap);
   for (int q = bblock * kBigWavesPerBlock + wv; q < count; q += bblocks * kBigWavesPerBlock) {
     const int g = big[q];
     const int s0 = start[g], n = start[g + 1] - s0;
     const bool staged = n <= kBigStage;
-    if (staged) for (int e = lane; e < n; e += 64) stage[wv][e] = perm[s0 + e];
-    __builtin_amdgcn_wave_barrier();            // one wave: its LDS writes are ordered before its later reads
-    for (int e = lane; e < n; e += 64) {
+    int nruns = 0;
+    if (staged) {
+      for (int e = lane; e < n; e += 64) stage[wv][e] = perm[s0 + e];
+      __builtin_amdgcn_wave_barrier();            // one wave: its LDS writes are ordered before its later reads
+      // the runs, in the order they lie in the segment: (first number, position)
+      for (int base = 0; base < n; base += 64) {
+        const int e = base + lane;
+        const int idx = e < n ? stage[wv][e] : 0, prev = (e > 0 && e < n) ? stage[wv][e - 1] : -2;
+        const bool head = e < n && (e == 0 || idx != prev + 1);
+        const u64 hm = __ballot(head);
+        if (head) {
+          const int r = nruns + __builtin_popcountll(hm & lt);
+          if (r < kBigRuns) { run_first[wv][r] = idx; run_pos[wv][r] = e; }
+        }
+        nruns += __builtin_popcountll(hm);
+      }
+      if (lane == 0 && nruns <= kBigRuns) run_pos[wv][nruns] = n;
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (staged && nruns <= kBigRuns) {
+      int seen = 0;                               // runs in front of this chunk
+      for (int base = 0; base < n; base += 64) {
+        const int e = base + lane;
+        const int idx = e < n ? stage[wv][e] : 0, prev = (e > 0 && e < n) ? stage[wv][e - 1] : -2;
+        const bool head = e < n && (e == 0 || idx != prev + 1);
+        const u64 hm = __ballot(head);
+        const int myrun = seen + __builtin_popcountll(hm & (lt | (1ull << lane))) - 1;     // (e < n: some head at or below)
+        seen += __builtin_popcountll(hm);
+        if (e >= n) continue;
+        const float2 p = load_pt(xy, stride, (size_t)idx);
+        const int myfirst = run_first[wv][myrun], off = e - run_pos[wv][myrun];
+        int dest = 0;
+        for (int r = 0; r < nruns; ++r) {           // (uniform reads: LDS broadcasts)
+          const int f = run_first[wv][r], len = run_pos[wv][r + 1] - run_pos[wv][r];
+          dest += (f < myfirst) ? len : 0;
+        }
+        pts[s0 + dest + off] = p;
+      }
+      continue;
+    }
+    for (int e = lane; e < n; e += 64) {          // many runs / a segment beyond the staging area: rank by counting
       const int mine = staged ? stage[wv][e] : perm[s0 + e];
       int rank = 0;
       if (staged) { for (int j = 0; j < n; ++j) rank += (stage[wv][j] < mine) ? 1 : 0; }
@@ -382,6 +432,11 @@ __device__ __forceinline__ int write_voxel(const GridDims &G, const LeafParams &
 
 // One lane per voxel: sequential sums in cloud order (float32 centroid, fp64 mean / Sxx), bucketed
 // copy of the raw points, cell record.
+// Round 4: the points of a wave's 64 consecutive voxels are one contiguous range of `pts`; the wave loads it into LDS with
+// coalesced reads, all in flight together, and every lane then walks its own voxel there.  Before, each lane streamed its
+// voxel from memory eight points at a time, and the kernel lasted as long as its fullest voxel's chain of load round
+// trips (128 points: sixteen of them).  Same additions in the same order: the sums are unchanged bit for bit.
+constexpr int kFinStage = 1536;               // points per wave in LDS (12 KiB; a wave whose voxels hold more streams from memory)
 __global__ void __launch_bounds__(256)
 map_finalize_kernel(GridDims G, LeafParams L,
                           const int *__restrict__ start,
@@ -389,38 +444,68 @@ map_finalize_kernel(GridDims G, LeafParams L,
                           int *__restrict__ npts_grid, int *__restrict__ counters /* unused */,
                           unsigned *__restrict__ occ /* (ng + 31) / 32 words: voxel in the search set */,
                           u64 *__restrict__ tiles, int tiles_w /* voxels with raw points, 8 x 8 per word (MapView::tiles) */) {
+  __shared__ float2 lp[4][kFinStage];
   const size_t ng = (size_t)G.div_x * G.div_y;
   size_t g = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
   const bool live = g < ng;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int s0 = 0, s1 = 0;
   if (live) { s0 = start[g]; s1 = start[g + 1]; }
   const int n = s1 - s0;
+  // the wave's range: from its first live lane's s0 to its last live lane's s1 (start[] is non-decreasing)
+  const int a = __shfl(s0, 0);
+  int b = s1;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) b = max(b, __shfl_xor(b, o));
+  const int m = b - a;
+  const bool in_lds = m <= kFinStage;
+  if (in_lds) {
+    for (int j0 = 0; j0 < m; j0 += 8 * 64) {      // eight coalesced loads per lane in flight
+      float2 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int j = j0 + u * 64 + lane; t[u] = pts[a + min(j, m - 1)]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int j = j0 + u * 64 + lane; if (j < m) lp[wv][j] = t[u]; }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
   int flag = 0;
   if (n > 0) {
     float fx = 0.f, fy = 0.f;
     double sx = 0, sy = 0, sxx = 0, sxy = 0, syy = 0, szz = 0;
     if (L.cov_init_identity) { sxx = 1.0; syy = 1.0; szz = 1.0; }
-    // eight loads in flight, consecutive addresses (map_order_kernel put the points in cloud order), and the NEXT eight issued
-    // before these are added up: the kernel ends with its fullest voxel, whose sums are one dependent chain by definition
-    float2 pb[8], pn[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) pb[u] = pts[min(s0 + u, s1 - 1)];
-    for (int s = s0; s < s1; s += 8) {
-      if (s + 8 < s1) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) pn[u] = pts[min(s + 8 + u, s1 - 1)];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        if (s + u >= s1) break;
-        const float2 p = pb[u];                 // strictly in cloud order: these sums define the voxel
+    if (in_lds) {
+      const float2 *q = &lp[wv][s0 - a];
+      for (int s = 0; s < n; ++s) {
+        const float2 p = q[s];                  // strictly in cloud order: these sums define the voxel
         fx += p.x; fy += p.y;
         const double X = (double)p.x, Y = (double)p.y;
         sx += X; sy += Y;
         sxx += X * X; sxy += X * Y; syy += Y * Y;
       }
+    } else {
+      // eight loads in flight, consecutive addresses (map_order_kernel put the points in cloud order), and the NEXT eight
+      // issued before these are added up
+      float2 pb[8], pn[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) pb[u] = pn[u];
+      for (int u = 0; u < 8; ++u) pb[u] = pts[min(s0 + u, s1 - 1)];
+      for (int s = s0; s < s1; s += 8) {
+        if (s + 8 < s1) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) pn[u] = pts[min(s + 8 + u, s1 - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (s + u >= s1) break;
+          const float2 p = pb[u];
+          fx += p.x; fy += p.y;
+          const double X = (double)p.x, Y = (double)p.y;
+          sx += X; sy += Y;
+          sxx += X * X; sxy += X * Y; syy += Y * Y;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pb[u] = pn[u];
+      }
     }
     flag = write_voxel(G, L, g, n, fx, fy, sx, sy, sxx, sxy, syy, szz, cent, rec, counters);
     const int vy = (int)(g / (size_t)G.div_x), vx = (int)(g - (size_t)vy * G.div_x);
