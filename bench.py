@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--moving-every", type=int, default=8, help="moving-local-map leg: the cloud's voxel bounding box moves every k-th step")
     ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state side figure (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--libm-f32", type=int, default=None, choices=[0, 1], help="override ndt_params.libm_f32 of the preset (A/B of the float32 cos / sin model)")
     ap.add_argument("--no-single-scan", action="store_true", help="skip the side figures (configs[1] latency, C5 leg, rows f1-f3)")
     ap.add_argument("--cpu-sample", type=int, default=256, help="matches timed on the host cores")
     ap.add_argument("--cpu-reps", type=int, default=5, help="times the CPU sample is run (median reported)")
@@ -257,6 +258,8 @@ def main():
     stream, ctx = streams[0], mctx[0]
     torch.cuda.set_stream(stream)
     prm = capi.default_params(resolution=cfg["resolution"])     # PCL 1.10 preset; otherwise ndt_mapping.launch:32-36
+    if args.libm_f32 is not None:
+        prm.libm_f32 = args.libm_f32
     d_map = torch.from_numpy(map_xy).to(dev)
     nbuf = args.inflight + 1                               # map and result buffers: a step's buffers are free again nbuf steps later
     d_res2 = [torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev) for _ in range(nbuf)]

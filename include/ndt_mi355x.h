@@ -60,6 +60,12 @@ typedef struct ndt_params {
   int    mt_max_iter;       /* 10    */
   double mt_mu;             /* 1e-4  */
   double mt_nu;             /* 0.9   */
+  int    libm_f32;          /* float32 cos / sin of a trial's yaw, the entries of final_transformation_ (Eigen's
+                               AngleAxisf::toRotationMatrix calls std::cos / std::sin on a float):
+                               1: glibc >= 2.28's cosf / sinf (x86-64, FMA build: what Ubuntu 20.04 / 22.04 run), restated
+                                  operation for operation and equal to libm on all 2.2e9 floats |x| < 120
+                                  (tests/test_libm_f32.py); 0: correctly rounded (differs from glibc by one ulp in 1.3 % of
+                                  the angles).  asinf / acosf / atan2f stay modelled as correctly rounded: DESIGN.md 2 */
 } ndt_params;
 
 /* Result of one scan-to-map match = everything src/PoseEstimator.cpp:28-64 reads back from
@@ -109,9 +115,10 @@ typedef struct ndt_map ndt_map;
  * reference compiles only against PCL <= 1.10, include/ndt_slam/PoseEstimator.h:72-73):
  *   ndt_params_pcl110   PCL 1.9 / 1.10 (Ubuntu 20.04, the likely build): VoxelGridCovariance::Leaf() starts
  *                       cov_ at the identity (cov_init_identity = 1), (n-1)/n normalisation
- *                       (cov_unbiased = 0), SSE transformPointCloud (transform_sse = 1)
- *   ndt_params_pcl18    PCL <= 1.8: the same voxel statistics, scalar transformPointCloud (transform_sse = 0)
- *   ndt_params_pcl_new  PCL >= 1.11: cov_ starts at zero, /(n-1) (cov_unbiased = 1), SSE transform
+ *                       (cov_unbiased = 0), SSE transformPointCloud (transform_sse = 1), glibc 2.31 (libm_f32 = 1)
+ *   ndt_params_pcl18    PCL <= 1.8: the same voxel statistics, scalar transformPointCloud (transform_sse = 0); its
+ *                       platform (Ubuntu 18.04, glibc 2.27) has an older sinf / cosf: modelled (libm_f32 = 0)
+ *   ndt_params_pcl_new  PCL >= 1.11: cov_ starts at zero, /(n-1) (cov_unbiased = 1), SSE transform, libm_f32 = 1
  * ndt_default_params is ndt_params_pcl110. */
 int ndt_default_params(ndt_params *p);
 int ndt_params_pcl110(ndt_params *p);

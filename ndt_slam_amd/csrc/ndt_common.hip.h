@@ -29,6 +29,7 @@ struct MapView {
 struct OptParams {
   double step_size, trans_eps, snap_thresh, mt_mu, mt_nu;
   int max_iter, conv_ge, stale_h_ang, mt_max_iter;
+  int libm_f32;                 // ndt_params::libm_f32: the float32 cos / sin of a trial as glibc computes them (ndt_libm_f32.hip.h)
 };
 
 struct Tf32 { float c, s, tx, ty; };
@@ -115,14 +116,19 @@ __device__ __forceinline__ float2 load_pt(const float *xy, size_t stride, size_t
 }
 
 // float32 matrix of the fp64 parameter vector (a4): Translation3f(float(p0), float(p1), 0) *
-// AngleAxisf(float(p2), Z); std::cos/std::sin(float) modelled as correctly rounded.
-__device__ __forceinline__ Tf32 tf_from_p(const double p[3]) {
+// AngleAxisf(float(p2), Z); std::cos / std::sin(float): glibc's cosf / sinf (libm_f32) or modelled as correctly rounded.
+__device__ __forceinline__ Tf32 tf_from_p(const double p[3], int libm_f32) {
   Tf32 t;
   float yaw = (float)p[2];
-  double sd, cd;
-  sincos((double)yaw, &sd, &cd);
-  t.c = (float)cd;
-  t.s = (float)sd;
+  if (libm_f32) {
+    t.c = sincosf_glibc(yaw, 1);
+    t.s = sincosf_glibc(yaw, 0);
+  } else {
+    double sd, cd;
+    sincos_small((double)yaw, sd, cd);
+    t.c = (float)cd;
+    t.s = (float)sd;
+  }
   t.tx = (float)p[0];
   t.ty = (float)p[1];
   return t;
@@ -148,5 +154,5 @@ __device__ __forceinline__ bool finite2(float x, float y) {
 
 __device__ __forceinline__ void angle_cs(double snap, double yaw, double &c, double &s) {
   if (fabs(yaw) < snap) { c = 1.0; s = 0.0; }
-  else { sincos(yaw, &s, &c); }
+  else { sincos_small(yaw, s, c); }
 }

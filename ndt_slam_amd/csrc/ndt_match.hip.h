@@ -1222,6 +1222,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         if (need_tf && lane < 2) trial_transforms(L.S, L.P, lane, need_tf);
       }
       // meanwhile another wave fetches the number of registered helpers for the next pass
+      // (round 4: fetched a pass EARLIER -- while the pass computes, off this stretch -- the kernel is 5.5 % slower: a helper
+      //  that has just registered must be counted in at once)
       if (threadIdx.x == 64 && allow_helpers) L.sflag[1] = (int)rd32_fresh(&C->ready);
       __syncthreads();
       if (kProf && prof) {
@@ -1435,7 +1437,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
 // one partial record per workgroup, summed on the host in block order.
 template <bool SSE, bool INCL>
 __global__ void __launch_bounds__(256)
-ndt_eval_kernel(MapView M, double snap, const float *__restrict__ scan, size_t stride, int n,
+ndt_eval_kernel(MapView M, double snap, int libm_f32, const float *__restrict__ scan, size_t stride, int n,
                 double p0, double p1, double p2, double *__restrict__ partial /* grid x kAcc */) {
   __shared__ double sred[(4 + 1) * kAcc];
   __shared__ double etab[64];
@@ -1446,7 +1448,7 @@ ndt_eval_kernel(MapView M, double snap, const float *__restrict__ scan, size_t s
   if (threadIdx.x == 0) { no_ent[0].cent = make_float2(INFINITY, INFINITY); no_ent[0].mx = no_ent[0].my = 0; no_ent[0].i00 = no_ent[0].i01 = no_ent[0].i11 = 0; }
   __syncthreads();
   double p[3] = {p0, p1, p2};
-  Tf32 T = tf_from_p(p);
+  Tf32 T = tf_from_p(p, libm_f32);
   double cj, sj;
   angle_cs(snap, p2, cj, sj);
   Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};

@@ -38,6 +38,7 @@ namespace {
 
 thread_local std::string g_last_error;
 
+#include "ndt_libm_f32.hip.h"
 #include "ndt_common.hip.h"
 #include "ndt_point.hip.h"
 #include "ndt_optimizer.hip.h"
@@ -184,7 +185,7 @@ OptParams opt_of(const ndt_params &p) {
   OptParams o;
   o.step_size = p.step_size; o.trans_eps = p.trans_eps; o.snap_thresh = p.snap_thresh;
   o.mt_mu = p.mt_mu; o.mt_nu = p.mt_nu; o.max_iter = p.max_iter; o.conv_ge = p.conv_ge;
-  o.stale_h_ang = p.stale_h_ang; o.mt_max_iter = p.mt_max_iter;
+  o.stale_h_ang = p.stale_h_ang; o.mt_max_iter = p.mt_max_iter; o.libm_f32 = p.libm_f32;
   return o;
 }
 
@@ -319,21 +320,21 @@ static void params_common(ndt_params *p) {
 int ndt_params_pcl110(ndt_params *p) {      // PCL 1.9 / 1.10: Leaf() starts cov_ at the identity, biased
   if (!p) return NDT_E_ARG;                 // normalisation, SSE transformPointCloud
   params_common(p);
-  p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 1;
+  p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 1; p->libm_f32 = 1;
   return NDT_OK;
 }
 
 int ndt_params_pcl18(ndt_params *p) {       // PCL <= 1.8: the same voxel statistics, scalar transformPointCloud
   if (!p) return NDT_E_ARG;
   params_common(p);
-  p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 0;
+  p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 0; p->libm_f32 = 0;   // (Ubuntu 18.04's glibc 2.27 has another sinf)
   return NDT_OK;
 }
 
 int ndt_params_pcl_new(ndt_params *p) {     // PCL >= 1.11: cov_ starts at zero, unbiased /(n-1)
   if (!p) return NDT_E_ARG;
   params_common(p);
-  p->cov_unbiased = 1; p->cov_init_identity = 0; p->transform_sse = 1;
+  p->cov_unbiased = 1; p->cov_init_identity = 0; p->transform_sse = 1; p->libm_f32 = 1;
   return NDT_OK;
 }
 
@@ -1014,10 +1015,10 @@ int ndt_eval_at(ndt_ctx *ctx, const ndt_map *map, const float *scan, size_t n, s
     const bool sse = map->prm.transform_sse != 0, incl = map->prm.radius_inclusive != 0;
     const MapView &V = map->view; const double sn = map->prm.snap_thresh;
     const float *ds = (const float *)ctx->d_scan; double *dt = (double *)ctx->d_tmp;
-    if (sse && incl)       ndt_eval_kernel<true, true><<<grid, 256, 0, st>>>(V, sn, ds, stride, (int)n, p[0], p[1], p[2], dt);
-    else if (sse)          ndt_eval_kernel<true, false><<<grid, 256, 0, st>>>(V, sn, ds, stride, (int)n, p[0], p[1], p[2], dt);
-    else if (incl)         ndt_eval_kernel<false, true><<<grid, 256, 0, st>>>(V, sn, ds, stride, (int)n, p[0], p[1], p[2], dt);
-    else                   ndt_eval_kernel<false, false><<<grid, 256, 0, st>>>(V, sn, ds, stride, (int)n, p[0], p[1], p[2], dt);
+    if (sse && incl)       ndt_eval_kernel<true, true><<<grid, 256, 0, st>>>(V, sn, map->prm.libm_f32, ds, stride, (int)n, p[0], p[1], p[2], dt);
+    else if (sse)          ndt_eval_kernel<true, false><<<grid, 256, 0, st>>>(V, sn, map->prm.libm_f32, ds, stride, (int)n, p[0], p[1], p[2], dt);
+    else if (incl)         ndt_eval_kernel<false, true><<<grid, 256, 0, st>>>(V, sn, map->prm.libm_f32, ds, stride, (int)n, p[0], p[1], p[2], dt);
+    else                   ndt_eval_kernel<false, false><<<grid, 256, 0, st>>>(V, sn, map->prm.libm_f32, ds, stride, (int)n, p[0], p[1], p[2], dt);
   }
   HIP_TRY(ctx, hipGetLastError());
   double *hp = (double *)malloc((size_t)grid * kAcc * 8);

@@ -127,9 +127,26 @@ __device__ __forceinline__ void set_trial(AlignState &S, const OptParams &P, boo
 // workgroup waiting: lanes 0 and 1 of the wave compute them side by side (same code, different argument).
 __device__ __noinline__ void trial_transforms(AlignState &S, const OptParams &P, int lane, int need) {
   const double yaw = S.xt[2];
+  if (P.libm_f32) {
+    // the float32 matrix entries as glibc's cosf / sinf give them -- lane 0 the cosine, lane 1 the sine, one code path --
+    // then the fp64 angle terms (both lanes walk the short sincos together, lane 1 keeps them)
+    const float v = sincosf_glibc((float)yaw, lane == 0 ? 1 : 0);
+    double sn, cs;
+    sincos_small(yaw, sn, cs);
+    if (lane == 0) {
+      S.T.c = v; S.T.tx = (float)S.xt[0]; S.T.ty = (float)S.xt[1];
+      S.need_tf = 0;
+    } else {
+      S.T.s = v;
+      if (fabs(yaw) < P.snap_thresh) { cs = 1.0; sn = 0.0; }
+      S.cj = cs; S.sj = sn;
+      if (need & 2) { S.ch = cs; S.sh = sn; }
+    }
+    return;
+  }
   const double arg = lane == 0 ? (double)(float)yaw : yaw;
   double sn, cs;
-  sincos(arg, &sn, &cs);
+  sincos_small(arg, sn, cs);
   if (lane == 0) {
     S.T.c = (float)cs; S.T.s = (float)sn; S.T.tx = (float)S.xt[0]; S.T.ty = (float)S.xt[1];
     S.need_tf = 0;
@@ -266,7 +283,7 @@ __device__ __noinline__ void init_state(AlignState &S, const OptParams &P, const
   S.iters = 0; S.evals = 0; S.ref_evals = 0; S.converged = 0; S.step_iterations = 0;
   S.open_interval = 1; S.interval_converged = 0; S.pairs = 0.0; S.n_points = n_points;
   double pi[3] = {init[0], init[1], init[2]};
-  S.T = tf_from_p(pi);     // init_guess = Translation3f * AngleAxisf (src/PoseEstimator.cpp:22-24)
+  S.T = tf_from_p(pi, P.libm_f32);     // init_guess = Translation3f * AngleAxisf (src/PoseEstimator.cpp:22-24)
   // p0 = (translation, eulerAngles(0,1,2)) of the float matrix: (-0, 0, atan2f(s, c))
   S.p[0] = (double)S.T.tx; S.p[1] = (double)S.T.ty;
   S.p[2] = (double)(float)atan2((double)S.T.s, (double)S.T.c);

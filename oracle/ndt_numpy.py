@@ -111,10 +111,30 @@ class Cells:
         return np.array(pi, dtype=np.int64), np.array(ci, dtype=np.int64)
 
 
+# std::cos / std::sin on a float (Eigen's AngleAxisf): this machine's libm cosf / sinf -- the default preset's libm_f32 = 1 -- or
+# the correctly rounded value (libm_f32 = 0: the PCL <= 1.8 preset's model)
+LIBM_F32 = True
+_libm = None
+
+
+def cos_sin_f32(yaw):
+    global _libm
+    if not LIBM_F32:
+        return F(math.cos(float(yaw))), F(math.sin(float(yaw)))
+    if _libm is None:
+        import ctypes
+        import ctypes.util
+        _libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        for f in (_libm.cosf, _libm.sinf):
+            f.restype = ctypes.c_float
+            f.argtypes = [ctypes.c_float]
+    return F(_libm.cosf(float(yaw))), F(_libm.sinf(float(yaw)))
+
+
 def transform32(scan32, p, sse=True):
     """x' = R(yaw) x + t in float32 with the float32 matrix of the fp64 parameters (a4)."""
     yaw = F(p[2])
-    c = F(math.cos(float(yaw))); s = F(math.sin(float(yaw)))
+    c, s = cos_sin_f32(yaw)
     tx = F(p[0]); ty = F(p[1])
     x = scan32[:, 0].astype(F); y = scan32[:, 1].astype(F)
     if not sse:

@@ -51,9 +51,9 @@ static void params_common(ndt_oracle_params *p) {
  * scalar transformPointCloud; 2 = PCL >= 1.11: cov_ starts at zero, /(n-1). */
 void ndt_oracle_params_preset(ndt_oracle_params *p, int preset) {
   params_common(p);
-  if (preset == 2) { p->cov_unbiased = 1; p->cov_init_identity = 0; p->transform_sse = 1; }
-  else if (preset == 1) { p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 0; }
-  else { p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 1; }
+  if (preset == 2) { p->cov_unbiased = 1; p->cov_init_identity = 0; p->transform_sse = 1; p->libm_f32 = 1; }
+  else if (preset == 1) { p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 0; p->libm_f32 = 0; }   /* glibc 2.27: another sinf */
+  else { p->cov_unbiased = 0; p->cov_init_identity = 1; p->transform_sse = 1; p->libm_f32 = 1; }
 }
 
 void ndt_oracle_default_params(ndt_oracle_params *p) { ndt_oracle_params_preset(p, 0); }
@@ -300,12 +300,17 @@ typedef struct { float c, s, tx, ty; } tf32;
 
 /* float32 matrix from the fp64 parameter vector, as computeStepLengthMT builds
  * final_transformation_ = Translation3f(float(p0),float(p1),0) * AngleAxisf(float(p2), Z).
- * std::cos/std::sin on a float argument are modelled as correctly rounded. */
-static tf32 tf_from_p(const double p[3]) {
+ * std::cos/std::sin on a float argument: libm's cosf / sinf (libm_f32 = 1) or modelled as correctly rounded (0). */
+static tf32 tf_from_p(const ndt_oracle_params *prm, const double p[3]) {
   tf32 t;
   float yaw = (float)p[2];
-  t.c = (float)cos((double)yaw);
-  t.s = (float)sin((double)yaw);
+  if (prm->libm_f32) {            /* the platform's own float functions: what std::cos / std::sin (float) are on the reference's machine */
+    t.c = cosf(yaw);
+    t.s = sinf(yaw);
+  } else {
+    t.c = (float)cos((double)yaw);
+    t.s = (float)sin((double)yaw);
+  }
   t.tx = (float)p[0];
   t.ty = (float)p[1];
   return t;
@@ -425,7 +430,7 @@ static void transform_scan(const ndt_oracle_params *prm, const float *src, size_
 double ndt_oracle_eval_at(const ndt_oracle_map *m, const float *scan, size_t n, size_t stride,
                           const double p[3], double g[3], double H[9], double *pairs_out) {
   float *tr = (float *)malloc(2 * (n ? n : 1) * sizeof(float));
-  transform_scan(&m->prm, scan, n, stride, tf_from_p(p), tr);
+  transform_scan(&m->prm, scan, n, stride, tf_from_p(&m->prm, p), tr);
   angle_terms at; angle_cs(&m->prm, p[2], &at.cj, &at.sj); at.ch = at.cj; at.sh = at.sj;
   double H6[6], pr = 0;
   double s = eval_pass(m, scan, n, stride, tr, at, 1, g, H6, &pr);
@@ -599,7 +604,7 @@ static double step_length_mt(align_ctx *cx, const double x[3], double dir[3], do
   a_t = (step_max < a_t) ? step_max : a_t;           /* std::min(a_t, step_max) */
   a_t = (a_t < step_min) ? step_min : a_t;           /* std::max(a_t, step_min) */
   double x_t[3] = {x[0] + dir[0] * a_t, x[1] + dir[1] * a_t, x[2] + dir[2] * a_t};
-  cx->T = tf_from_p(x_t);
+  cx->T = tf_from_p(prm, x_t);
   transform_scan(prm, cx->scan, cx->n, cx->stride, cx->T, cx->trans);
   *score = derivatives(cx, x_t, 1, g, H);
   trace_push(cx, a_t, *score, g, x_t);
@@ -614,7 +619,7 @@ static double step_length_mt(align_ctx *cx, const double x[3], double dir[3], do
     a_t = (step_max < a_t) ? step_max : a_t;
     a_t = (a_t < step_min) ? step_min : a_t;
     x_t[0] = x[0] + dir[0] * a_t; x_t[1] = x[1] + dir[1] * a_t; x_t[2] = x[2] + dir[2] * a_t;
-    cx->T = tf_from_p(x_t);
+    cx->T = tf_from_p(prm, x_t);
     transform_scan(prm, cx->scan, cx->n, cx->stride, cx->T, cx->trans);
     *score = derivatives(cx, x_t, 0, g, H);
     trace_push(cx, a_t, *score, g, x_t);
@@ -699,9 +704,9 @@ double ndt_oracle_fitness(const ndt_oracle_map *m, const float *scan, size_t n, 
  * computeTransformation prologue: p = (translation, rotation().eulerAngles(0,1,2)) of the float matrix;
  * for a pure-Z rotation eulerAngles gives (-0, 0, atan2f(s, c)) (include/Eigen/src/Geometry/EulerAngles.h:87-107).
  * tests/test_eigen_pins.py holds this against the vendored Eigen's own answer. */
-static void init_guess(const double init[3], tf32 *T, double p[3]) {
+static void init_guess(const ndt_oracle_params *prm, const double init[3], tf32 *T, double p[3]) {
   double pinit[3] = {init[0], init[1], init[2]};
-  *T = tf_from_p(pinit);
+  *T = tf_from_p(prm, pinit);
   p[0] = (double)T->tx; p[1] = (double)T->ty;
   p[2] = (double)(float)atan2((double)T->s, (double)T->c);
   if (g_hooks.init_p) { float t4[4] = {T->c, T->s, T->tx, T->ty}; g_hooks.init_p(t4, p); }
@@ -720,7 +725,7 @@ int ndt_oracle_align(const ndt_oracle_map *m, const float *scan, size_t n, size_
 
   /* src/PoseEstimator.cpp:22-24: init_guess = Translation3f(tx,ty,0) * AngleAxisf(yaw, Z) */
   double p[3];
-  init_guess(init, &cx.T, p);
+  init_guess(prm, init, &cx.T, p);
   transform_scan(prm, scan, n, stride, cx.T, cx.trans);   /* transformPointCloud(output, output, guess) */
 
   double g[3], H[6], score;
@@ -977,12 +982,12 @@ int ndt_oracle_leaf(const ndt_oracle_params *prm, int n, const double sums[6], d
   return leaf_finalize(prm, n, sums[0], sums[1], sums[2], sums[3], sums[4], sums[5], mean, icov);
 }
 void ndt_oracle_inv3(const double m[9], double out[9]) { f2_inv3(m, out); }
-void ndt_oracle_init_guess(const double init[3], float T[4], double p[3]) {
-  tf32 t; init_guess(init, &t, p);
+void ndt_oracle_init_guess(const ndt_oracle_params *prm, const double init[3], float T[4], double p[3]) {
+  tf32 t; init_guess(prm, init, &t, p);
   T[0] = t.c; T[1] = t.s; T[2] = t.tx; T[3] = t.ty;
 }
-void ndt_oracle_step_matrix(const double p[3], float T[4]) {
-  tf32 t = tf_from_p(p);
+void ndt_oracle_step_matrix(const ndt_oracle_params *prm, const double p[3], float T[4]) {
+  tf32 t = tf_from_p(prm, p);
   T[0] = t.c; T[1] = t.s; T[2] = t.tx; T[3] = t.ty;
 }
 /* replace the fp64 part of the cell table (compact order of ndt_oracle_map_export) */

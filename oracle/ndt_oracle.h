@@ -56,6 +56,8 @@ typedef struct ndt_oracle_params {
   int    mt_max_iter;       /* (11) 10                                                         */
   double mt_mu;             /* (11) 1e-4                                                       */
   double mt_nu;             /* (11) 0.9                                                        */
+  int    libm_f32;          /* (12b) float32 cos / sin of a trial's yaw: 1: THIS machine's libm cosf / sinf (glibc:
+                                     the reference's platform; what Eigen's AngleAxisf calls); 0: correctly rounded */
 } ndt_oracle_params;
 
 /* Result of one match.  Layout shared with include/ndt_mi355x.h's ndt_result. */
@@ -197,8 +199,8 @@ void ndt_oracle_set_hooks(const ndt_oracle_hooks *h);                   /* NULL:
 int  ndt_oracle_leaf(const ndt_oracle_params *prm, int n, const double sums[6] /* sx sy sxx sxy syy szz */,
                      double mean[2], double icov[3]);                   /* 1 accepted, 0 / -1 rejected */
 void ndt_oracle_inv3(const double m[9], double out[9]);
-void ndt_oracle_init_guess(const double init[3], float T[4], double p[3]);
-void ndt_oracle_step_matrix(const double p[3], float T[4]);
+void ndt_oracle_init_guess(const ndt_oracle_params *prm, const double init[3], float T[4], double p[3]);
+void ndt_oracle_step_matrix(const ndt_oracle_params *prm, const double p[3], float T[4]);
 void ndt_oracle_map_override_cells(ndt_oracle_map *m, const double *mean, const double *icov, const int *npts);
 void ndt_oracle_map_export_sums(const ndt_oracle_map *m, double *out /* n_cells x 7 */);
 

@@ -108,8 +108,8 @@ def oracle_pins():
     L.ndt_oracle_leaf.restype = C.c_int
     L.ndt_oracle_leaf.argtypes = [C.POINTER(O.Params), C.c_int, vp, vp, vp]
     L.ndt_oracle_inv3.argtypes = [vp, vp]
-    L.ndt_oracle_init_guess.argtypes = [vp, vp, vp]
-    L.ndt_oracle_step_matrix.argtypes = [vp, vp]
+    L.ndt_oracle_init_guess.argtypes = [C.POINTER(O.Params), vp, vp, vp]
+    L.ndt_oracle_step_matrix.argtypes = [C.POINTER(O.Params), vp, vp]
     L.ndt_oracle_map_override_cells.argtypes = [vp, vp, vp, vp]
     L.ndt_oracle_map_export_sums.argtypes = [vp, vp]
     L.ndt_oracle_set_hooks.argtypes = [vp]

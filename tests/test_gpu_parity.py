@@ -368,6 +368,35 @@ def test_c1_matches_oracle_with_same_step_sequence(gpu, oracle, c1_world):
         assert single.tobytes() == res[b].tobytes()                                # batch == single, deterministic
 
 
+def test_device_cos_sin_are_the_platforms(gpu, c1_world):
+    """ndt_params::libm_f32: the float32 matrix entries of the last trial, T00 / T10 = cos / sin of float(p_yaw) (the final
+    parameter vector is that trial's), must be what THIS machine's libm returns for cosf / sinf -- the device's restatement
+    of glibc's algorithm (ndt_libm_f32.hip.h) on the angles real matches end at, incl. the +-90 / +-180 degree strata --
+    and, with libm_f32 = 0, the correctly rounded values."""
+    import ctypes
+    import ctypes.util
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    libm = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+    for f in (libm.cosf, libm.sinf):
+        f.restype = ctypes.c_float; f.argtypes = [ctypes.c_float]
+    scans, off, truths, inits = sf.batch(0, 96)
+    n_model_differs = 0
+    for mode in (1, 0):
+        gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"], libm_f32=mode))
+        res = gm.align_batch(scans, off, inits)
+        assert np.all(res["iters"] > 0)
+        for r in res:
+            yf = np.float32(r["p"][2])
+            plat = (np.float32(libm.cosf(float(yf))), np.float32(libm.sinf(float(yf))))
+            model = (np.float32(math.cos(float(yf))), np.float32(math.sin(float(yf))))
+            want = plat if mode else model
+            assert (r["T00"], r["T10"]) == want, (mode, yf, r["T00"], r["T10"], want)
+            n_model_differs += plat != model
+        gm.close()
+    assert capi.default_params().libm_f32 == 1 and capi.default_params(preset="pcl18").libm_f32 == 0
+
+
 def test_yaw_strata_near_90_and_180(gpu, oracle, c1_world):
     """a9: the asin/acos extraction near +-90 / +-180 deg must follow the same float32 branches."""
     capi, ctx = gpu
