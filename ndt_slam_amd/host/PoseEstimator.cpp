@@ -90,8 +90,14 @@ double PoseEstimator::estimatePose(Pose2D &initPose, Pose2D &estPose, Matrix3d &
   // :22-28 init guess from the odometry prediction (degrees -> radians), align
   const double init[3] = {initPose.tx, initPose.ty, DEG2RAD(initPose.th)};
   if (ndt_align(ctx_, map_, filtered.data(), filtered.size() / 2, 8, init, &last_) != NDT_OK) return kFailed;
-  // :29-36 pose from the float32 matrix (the asin/acos branches run inside the library)
-  estPose.setPose(last_.pose[0], last_.pose[1], RAD2DEG(last_.pose[2]));
+  // :29-36 pose from the float32 matrix: the reference's branches with THIS platform's asinf / acosf (std::asin / std::acos on
+  // a float), not the correctly-rounded model behind last_.pose[2] -- what the reference reports on the same machine
+  const float t00 = last_.T00, t10 = last_.T10;
+  double theta;
+  if (t00 > 0 && (t10 > 0 || t10 < 0)) theta = std::asin(t10);
+  else if (t00 < 0 && t10 > 0) theta = std::acos(t00);
+  else theta = std::acos(t00) * (-1.0);
+  estPose.setPose(last_.T03, last_.T13, RAD2DEG(theta));
   // :43-46 fitness score, sentinel when not converged
   double cost = last_.fitness;
   if (!last_.converged) cost = kFailed;

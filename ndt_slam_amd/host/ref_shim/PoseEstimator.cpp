@@ -2,6 +2,7 @@
 // (tests/test_ref_shim_compiles.py); the text below the marker is identical to the listing there.
 // ---- listing ----
 #include "PoseEstimator.h"
+#include <cmath>
 
 // PoseEstimator.h:91-128 -- double -> float32 copy of the scan points, z = 0 (row a0)
 static void lps_to_cloud(const std::vector<LPoint2D> &lps, pcl::PointCloud<pcl::PointXYZ> &cloud) {
@@ -54,9 +55,15 @@ double PoseEstimator::estimatePose(Pose2D &initPose, Pose2D &estPose, Eigen::Mat
     return kFailed;
   }
 
-  // :29-36 (the asin/acos branches of :31-35 ran on the float32 entries inside the library;
-  // r.T00/T10/T03/T13 are there for a shim that wants to re-run them)
-  estPose.setPose(r.pose[0], r.pose[1], RAD2DEG(r.pose[2]));
+  // :29-36 -- the yaw comes from the float32 matrix entries through std::asin / std::acos on a float, i.e. THIS platform's
+  // asinf / acosf (glibc's are not correctly rounded: 7.5 % of the arguments differ by an ulp from the model behind
+  // r.pose[2]).  Re-run here on r.T00 / r.T10 so that the drop-in reports exactly what the reference would on the same machine.
+  const float t00 = r.T00, t10 = r.T10;
+  double theta;
+  if (t00 > 0 && (t10 > 0 || t10 < 0)) theta = std::asin(t10);
+  else if (t00 < 0 && t10 > 0) theta = std::acos(t00);
+  else theta = std::acos(t00) * (-1.0);
+  estPose.setPose(r.T03, r.T13, RAD2DEG(theta));
 
   // :43-46
   double cost = r.fitness;

@@ -76,6 +76,29 @@ def approximate_voxel_grid(xy32, leaf):
     return np.array(out, dtype=np.float32).reshape(-1, 2)
 
 
+_LIBM = None
+
+
+def yaw_from_T_platform(T00, T10):
+    """src/PoseEstimator.cpp:31-35 on the float32 matrix entries with THIS platform's asinf / acosf (what std::asin / std::acos
+    are for a float argument): the reference's own lines run on the library's T00 / T10, so the reported yaw is the reference's
+    on the same machine (ndt_result.pose[2] holds the correctly-rounded model of the same branches)."""
+    global _LIBM
+    if _LIBM is None:
+        import ctypes
+        import ctypes.util
+        _LIBM = ctypes.CDLL(ctypes.util.find_library("m") or "libm.so.6")
+        for f in (_LIBM.asinf, _LIBM.acosf):
+            f.restype = ctypes.c_float
+            f.argtypes = [ctypes.c_float]
+    c, s = float(np.float32(T00)), float(np.float32(T10))
+    if c > 0 and s != 0:
+        return float(_LIBM.asinf(s))
+    if c < 0 and s > 0:
+        return float(_LIBM.acosf(c))
+    return float(_LIBM.acosf(c)) * (-1.0)
+
+
 class PoseEstimator:
     """Drop-in for the reference class of the same name."""
 
@@ -119,7 +142,7 @@ class PoseEstimator:
         except capi.NdtError:
             return NOT_CONVERGED_COST, est, cov
         self.last_result = r
-        est.setPose(float(r["pose"][0]), float(r["pose"][1]), RAD2DEG(float(r["pose"][2])))   # :29-36
+        est.setPose(float(r["T03"]), float(r["T13"]), RAD2DEG(yaw_from_T_platform(r["T00"], r["T10"])))   # :29-36
         cost = float(r["fitness"])                                                  # :43
         if not r["converged"]:                                                      # :44-46
             cost = NOT_CONVERGED_COST
