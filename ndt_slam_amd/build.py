@@ -11,6 +11,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
          "-ffp-contract=off",            # explicit fma only (see the header of the .hip file)
+         "-fhip-fp32-correctly-rounded-divide-sqrt",   # (the default, spelled out: ndt_libm_f32.hip.h restates float code of Eigen / glibc)
          "-fno-fast-math", "-fgpu-rdc" if False else "-fno-gpu-rdc",
          "-I" + os.path.join(ROOT, "include")]
 

@@ -582,6 +582,10 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
   constexpr int kRun = 20;                                             // counters per thread: five 16-byte words
   constexpr int kHistWords = (kRegionCells + 1 + 3) & ~3;              // ncell + 1 counters (last: outside the window), padded
   static_assert(kRun * kBlock >= kHistWords && kRun % 4 == 0, "every counter belongs to a thread's run");
+  // the optimiser's start first, while nothing else is live (round 4: called behind the loads it made this routine spill its
+  // twenty point registers around the call once init_state had grown by Eigen's rotation() -- 192 instead of 96 bytes of
+  // scratch per lane and 1.7 % on the whole kernel; the scan's first touch is long enough without it)
+  if (threadIdx.x == 0) init_state(L.S, P, init, (double)n);
   float2 pt[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) pt[u] = gld_f2(scan + min((int)threadIdx.x + u * kBlock, n - 1));
@@ -597,7 +601,6 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
   }
   if (threadIdx.x < kRegionCells / 32) wmap[threadIdx.x] = 0u;
   if (threadIdx.x == 0) {
-    init_state(L.S, P, init, (double)n);
     L.sbox[0] = INT_MAX; L.sbox[1] = INT_MAX; L.sbox[2] = INT_MIN; L.sbox[3] = INT_MIN;
   }
   __syncthreads();

@@ -284,9 +284,10 @@ __device__ __noinline__ void init_state(AlignState &S, const OptParams &P, const
   S.open_interval = 1; S.interval_converged = 0; S.pairs = 0.0; S.n_points = n_points;
   double pi[3] = {init[0], init[1], init[2]};
   S.T = tf_from_p(pi, P.libm_f32);     // init_guess = Translation3f * AngleAxisf (src/PoseEstimator.cpp:22-24)
-  // p0 = (translation, eulerAngles(0,1,2)) of the float matrix: (-0, 0, atan2f(s, c))
+  // p0 = (translation, rotation().eulerAngles(0,1,2)) of the float matrix: (-0, 0, yaw) -- the yaw as Eigen and the platform's
+  // atan2f compute it (libm_f32: ndt_libm_f32.hip.h) or modelled as atan2f(s, c) correctly rounded
   S.p[0] = (double)S.T.tx; S.p[1] = (double)S.T.ty;
-  S.p[2] = (double)(float)atan2((double)S.T.s, (double)S.T.c);
+  S.p[2] = P.libm_f32 ? (double)eigen_init_yaw(S.T.c, S.T.s) : (double)(float)atan2((double)S.T.s, (double)S.T.c);
   S.xt[0] = S.p[0]; S.xt[1] = S.p[1]; S.xt[2] = S.p[2];
   S.dir[0] = S.dir[1] = S.dir[2] = 0.0; S.a_t = 0.0;
   angle_cs(P.snap_thresh, S.p[2], S.cj, S.sj);

@@ -131,6 +131,102 @@ def cos_sin_f32(yaw):
     return F(_libm.cosf(float(yaw))), F(_libm.sinf(float(yaw)))
 
 
+def _libm_f32():
+    cos_sin_f32(F(0.0))
+    for name, nargs in (("atan2f", 2),):
+        f = getattr(_libm, name)
+        if f.restype is not __import__("ctypes").c_float:
+            import ctypes
+            f.restype = ctypes.c_float
+            f.argtypes = [ctypes.c_float] * nargs
+    return _libm
+
+
+def eigen_init_yaw(c, s):
+    """The initial yaw as computeTransformation's prologue gets it: Affine3f.rotation().eulerAngles(0, 1, 2)[2] for the guess
+    matrix of a z rotation.  rotation() = U V^T of a float32 two-sided Jacobi SVD of the linear part (Eigen 3.3.90:
+    Geometry/Transform.h:1088-1121, SVD/JacobiSVD.h:663-790, misc/RealSvd2x2.h, Jacobi/Jacobi.h); every operation below is a
+    float32 operation in Eigen's order (3-term sums as a0 + (a1 + a2)); atan2f / sinf / cosf are this machine's libm."""
+    lm = _libm_f32()
+    one, zero = F(1.0), F(0.0)
+    m22 = F(F(one - c) + c)
+    W = np.array([[c, -s, zero], [s, c, zero], [zero, zero, m22]], dtype=F)
+    U = np.eye(3, dtype=F); V = np.eye(3, dtype=F)
+    scale = F(np.abs(W).max())
+    if scale == 0:
+        scale = one
+    W = (W / scale).astype(F)
+    eps2, tiny = F(2.0) * np.finfo(F).eps, np.finfo(F).tiny
+    max_diag = F(max(abs(W[0, 0]), abs(W[1, 1]), abs(W[2, 2])))
+
+    def rot(x, y, cc, ss):                       # x <- c x + s y ; y <- -s x + c y   (element-wise float32)
+        if cc == one and ss == zero:
+            return x, y
+        return (F(cc) * x + F(ss) * y).astype(F), (F(-ss) * x + F(cc) * y).astype(F)
+
+    for _ in range(64):
+        finished = True
+        for pp in (1, 2):
+            for q in range(pp):
+                thr = max(tiny, F(eps2 * max_diag))
+                if not (abs(W[pp, q]) > thr or abs(W[q, pp]) > thr):
+                    continue
+                finished = False
+                m = np.array([[W[pp, pp], W[pp, q]], [W[q, pp], W[q, q]]], dtype=F)
+                t = F(m[0, 0] + m[1, 1]); d = F(m[1, 0] - m[0, 1])
+                if abs(d) < tiny:
+                    r1c, r1s = one, zero
+                else:
+                    u = F(t / d); tmp = F(np.sqrt(F(one + F(u * u))))
+                    r1s = F(one / tmp); r1c = F(u / tmp)
+                m[0], m[1] = rot(m[0].copy(), m[1].copy(), r1c, r1s)
+                deno = F(F(2.0) * abs(m[0, 1]))
+                if deno < tiny:
+                    jrc, jrs = one, zero
+                else:
+                    tau = F(F(m[0, 0] - m[1, 1]) / deno); w = F(np.sqrt(F(F(tau * tau) + one)))
+                    tt = F(one / F(tau + w)) if tau > 0 else F(one / F(tau - w))
+                    sign_t = one if tt > 0 else F(-1.0)
+                    n = F(one / F(np.sqrt(F(F(tt * tt) + one))))
+                    jrs = F(F(F(F(-sign_t) * F(m[0, 1] / abs(m[0, 1]))) * abs(tt)) * n); jrc = n
+                oc, os_ = jrc, F(-jrs)
+                jlc = F(F(r1c * oc) - F(r1s * os_)); jls = F(F(r1c * os_) + F(r1s * oc))
+                W[pp], W[q] = rot(W[pp].copy(), W[q].copy(), jlc, jls)
+                U[:, pp], U[:, q] = rot(U[:, pp].copy(), U[:, q].copy(), jlc, jls)
+                W[:, pp], W[:, q] = rot(W[:, pp].copy(), W[:, q].copy(), jrc, F(-jrs))
+                V[:, pp], V[:, q] = rot(V[:, pp].copy(), V[:, q].copy(), jrc, F(-jrs))
+                max_diag = F(max(max_diag, abs(W[pp, pp]), abs(W[q, q])))
+        if finished:
+            break
+    sv = np.abs(np.diag(W)).astype(F)
+    for i in range(3):
+        if W[i, i] < 0:
+            U[:, i] = -U[:, i]
+    sv = (sv * scale).astype(F)
+    for i in range(3):
+        pos = i + int(np.argmax(sv[i:]))          # the first maximum, as maxCoeff
+        if sv[pos] == 0:
+            break
+        if pos != i:
+            sv[[i, pos]] = sv[[pos, i]]; U[:, [i, pos]] = U[:, [pos, i]]; V[:, [i, pos]] = V[:, [pos, i]]
+
+    def mul_t(A, B):                              # A B^T, coefficient = a0 + (a1 + a2)
+        out = np.zeros((3, 3), dtype=F)
+        for i in range(3):
+            for j in range(3):
+                out[i, j] = F(F(A[i, 0] * B[j, 0]) + F(F(A[i, 1] * B[j, 1]) + F(A[i, 2] * B[j, 2])))
+        return out
+    P = mul_t(U, V)
+    h = lambda a, b, cc: F(P[0, a] * F(F(P[1, b] * P[2, cc]) - F(P[1, cc] * P[2, b])))
+    x = F(F(h(0, 1, 2) - h(1, 0, 2)) + h(2, 0, 1))
+    Mx = U.copy(); Mx[:, 0] = (Mx[:, 0] / x).astype(F)
+    R = mul_t(Mx, V)
+    res0 = F(lm.atan2f(float(R[1, 2]), float(R[2, 2])))
+    c1, s1 = cos_sin_f32(res0)
+    num = F(F(s1 * R[2, 0]) - F(c1 * R[1, 0])); den = F(F(c1 * R[1, 1]) - F(s1 * R[2, 1]))
+    return F(-F(lm.atan2f(float(num), float(den))))
+
+
 def transform32(scan32, p, sse=True):
     """x' = R(yaw) x + t in float32 with the float32 matrix of the fp64 parameters (a4)."""
     yaw = F(p[2])
@@ -254,7 +350,8 @@ def align(cells, scan32, init, resolution, step_size=0.1, trans_eps=0.01, max_it
     scan32 = np.ascontiguousarray(scan32, dtype=F)
     log = []
     trans, T = transform32(scan32, init, sse)
-    p = np.array([float(T[2]), float(T[3]), float(F(math.atan2(float(T[1]), float(T[0]))))])
+    yaw0 = eigen_init_yaw(F(T[0]), F(T[1])) if LIBM_F32 else F(math.atan2(float(T[1]), float(T[0])))
+    p = np.array([float(T[2]), float(T[3]), float(yaw0)])
     state = {"yaw_h": p[2], "evals": 0}
 
     def derivs(pp, tr, refresh_h):

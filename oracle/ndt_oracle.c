@@ -700,15 +700,107 @@ double ndt_oracle_fitness(const ndt_oracle_map *m, const float *scan, size_t n, 
   return fitness_pass(m, scan, n, stride, T);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* The initial yaw as Eigen computes it (libm_f32 = 1).  computeTransformation's prologue reads */
+/* the angles back from the guess matrix: Affine3f.rotation().eulerAngles(0, 1, 2).             */
+/* rotation() of an AFFINE transform is not its linear part: computeRotationScaling runs         */
+/* JacobiSVD<Matrix3f>(linear, FullU | FullV), x = det(U V^T), U.col(0) /= x, R = U V^T          */
+/* (include/Eigen/src/Geometry/Transform.h:1088-1121, SVD/JacobiSVD.h:663-790,                   */
+/* misc/RealSvd2x2.h:19-49, Jacobi/Jacobi.h:94-125 and :54-59) -- restated here in float32,      */
+/* operation for operation, for the linear part [[c,-s,0],[s,c,0],[0,0,(1-c)+c]] of a z rotation */
+/* (3-term products as a0 + (a1 + a2): Eigen's unrolled reduction, Core/Redux.h:99-113), then    */
+/* eulerAngles(0,1,2) (Geometry/EulerAngles.h:87-107) with the platform's atan2f / sinf / cosf.  */
+/* Equal to the vendored Eigen's answer on 2e7 yaws incl. the +-90 / +-180 degree strata         */
+/* (tests/golden/make_eigen_golden.py) and on every case of tests/golden/eigen_golden.npz.       */
+/* ------------------------------------------------------------------------------------------ */
+static void eig_apply_rot(float *x, int ix, float *y, int iy, int n, float c, float s) {
+  if (c == 1.0f && s == 0.0f) return;
+  for (int i = 0; i < n; ++i) {
+    float xi = x[i * ix], yi = y[i * iy];
+    float a = c * xi, b = s * yi, d = -s * xi, e = c * yi;
+    x[i * ix] = a + b; y[i * iy] = d + e;
+  }
+}
+static void eigen_rotation_z(float c, float s, float m22, float R[9]) {
+  float W[9] = {c, -s, 0, s, c, 0, 0, 0, m22};
+  float U[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  float scale = 0;
+  for (int i = 0; i < 9; ++i) { float a = fabsf(W[i]); if (a > scale) scale = a; }
+  if (scale == 0) scale = 1;
+  for (int i = 0; i < 9; ++i) W[i] = W[i] / scale;
+  const float precision = 2 * FLT_EPSILON, tiny = FLT_MIN;
+  float maxDiag = fmaxf(fabsf(W[0]), fmaxf(fabsf(W[4]), fabsf(W[8])));
+  int finished = 0;
+  for (int guard = 0; !finished && guard < 64; ++guard) {
+    finished = 1;
+    for (int p = 1; p < 3; ++p) for (int q = 0; q < p; ++q) {
+      float thr = fmaxf(tiny, precision * maxDiag);
+      if (!(fabsf(W[3 * p + q]) > thr || fabsf(W[3 * q + p]) > thr)) continue;
+      finished = 0;
+      float mm[4] = {W[3 * p + p], W[3 * p + q], W[3 * q + p], W[3 * q + q]};          /* real_2x2_jacobi_svd */
+      float t = mm[0] + mm[3], d = mm[2] - mm[1], r1c, r1s;
+      if (fabsf(d) < tiny) { r1s = 0; r1c = 1; }
+      else { float u = t / d; float tmp = sqrtf(1.0f + u * u); r1s = 1.0f / tmp; r1c = u / tmp; }
+      eig_apply_rot(&mm[0], 1, &mm[2], 1, 2, r1c, r1s);
+      float jrc, jrs;                                                                    /* makeJacobi(m00, m01, m11) */
+      { float deno = 2.0f * fabsf(mm[1]);
+        if (deno < tiny) { jrc = 1; jrs = 0; }
+        else { float tau = (mm[0] - mm[3]) / deno; float w = sqrtf(tau * tau + 1.0f); float tt;
+          if (tau > 0) tt = 1.0f / (tau + w); else tt = 1.0f / (tau - w);
+          float sign_t = tt > 0 ? 1.0f : -1.0f; float n = 1.0f / sqrtf(tt * tt + 1.0f);
+          jrs = -sign_t * (mm[1] / fabsf(mm[1])) * fabsf(tt) * n; jrc = n; } }
+      float jlc, jls;                                                                    /* rot1 * j_right^T */
+      { float oc = jrc, os = -jrs; jlc = r1c * oc - r1s * os; jls = r1c * os + r1s * oc; }
+      eig_apply_rot(&W[3 * p], 1, &W[3 * q], 1, 3, jlc, jls);
+      eig_apply_rot(&U[p], 3, &U[q], 3, 3, jlc, jls);
+      eig_apply_rot(&W[p], 3, &W[q], 3, 3, jrc, -jrs);
+      eig_apply_rot(&V[p], 3, &V[q], 3, 3, jrc, -jrs);
+      maxDiag = fmaxf(maxDiag, fmaxf(fabsf(W[3 * p + p]), fabsf(W[3 * q + q])));
+    }
+  }
+  float sv[3];
+  for (int i = 0; i < 3; ++i) { float a = W[4 * i]; sv[i] = fabsf(a); if (a < 0) for (int r = 0; r < 3; ++r) U[3 * r + i] = -U[3 * r + i]; }
+  for (int i = 0; i < 3; ++i) sv[i] *= scale;
+  for (int i = 0; i < 3; ++i) {
+    int pos = 0; float mx = sv[i];
+    for (int k = i + 1; k < 3; ++k) if (sv[k] > mx) { mx = sv[k]; pos = k - i; }
+    if (mx == 0) break;
+    if (pos) { pos += i; float tf = sv[i]; sv[i] = sv[pos]; sv[pos] = tf;
+      for (int r = 0; r < 3; ++r) { float a = U[3 * r + pos]; U[3 * r + pos] = U[3 * r + i]; U[3 * r + i] = a;
+                                    a = V[3 * r + pos]; V[3 * r + pos] = V[3 * r + i]; V[3 * r + i] = a; } }
+  }
+  float P[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    float a0 = U[3 * i] * V[3 * j], a1 = U[3 * i + 1] * V[3 * j + 1], a2 = U[3 * i + 2] * V[3 * j + 2]; float a12 = a1 + a2; P[3 * i + j] = a0 + a12; }
+  float x;
+  { float h0 = P[4] * P[8], h1 = P[5] * P[7], g0 = P[3] * P[8], g1 = P[5] * P[6], f0 = P[3] * P[7], f1 = P[4] * P[6];
+    float d0 = h0 - h1, d1 = g0 - g1, d2 = f0 - f1; float t0 = P[0] * d0, t1 = P[1] * d1, t2 = P[2] * d2; float u = t0 - t1; x = u + t2; }
+  float M[9]; memcpy(M, U, sizeof(M));
+  for (int r = 0; r < 3; ++r) M[3 * r] = M[3 * r] / x;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    float a0 = M[3 * i] * V[3 * j], a1 = M[3 * i + 1] * V[3 * j + 1], a2 = M[3 * i + 2] * V[3 * j + 2]; float a12 = a1 + a2; R[3 * i + j] = a0 + a12; }
+}
+static float eigen_init_yaw(float c, float s) {
+  float omc = 1.0f - c, m22 = omc + c;                     /* AngleAxisf::toRotationMatrix: cos_axis.z * axis.z + c */
+  float R[9];
+  eigen_rotation_z(c, s, m22, R);
+  float res0 = atan2f(R[5], R[8]);
+  float s1 = sinf(res0), c1 = cosf(res0);
+  float n0 = s1 * R[6], n1 = c1 * R[3], d0 = c1 * R[4], d1 = s1 * R[7];
+  return -atan2f(n0 - n1, d0 - d1);
+}
+
 /* src/PoseEstimator.cpp:22-24 init_guess = Translation3f(tx,ty,0) * AngleAxisf(yaw, Z), then the
  * computeTransformation prologue: p = (translation, rotation().eulerAngles(0,1,2)) of the float matrix;
- * for a pure-Z rotation eulerAngles gives (-0, 0, atan2f(s, c)) (include/Eigen/src/Geometry/EulerAngles.h:87-107).
- * tests/test_eigen_pins.py holds this against the vendored Eigen's own answer. */
+ * for a pure-Z rotation eulerAngles gives (-0, 0, yaw) (include/Eigen/src/Geometry/EulerAngles.h:87-107) with yaw from
+ * eigen_init_yaw (libm_f32 = 1: bit-equal to the vendored Eigen's answer, tests/test_eigen_pins.py) or modelled as
+ * atan2f(s, c) correctly rounded (libm_f32 = 0: within 2.4e-7 rad of it). */
 static void init_guess(const ndt_oracle_params *prm, const double init[3], tf32 *T, double p[3]) {
   double pinit[3] = {init[0], init[1], init[2]};
   *T = tf_from_p(prm, pinit);
   p[0] = (double)T->tx; p[1] = (double)T->ty;
-  p[2] = (double)(float)atan2((double)T->s, (double)T->c);
+  if (prm->libm_f32) p[2] = (double)eigen_init_yaw(T->c, T->s);      /* Eigen's own arithmetic + the platform's libm */
+  else p[2] = (double)(float)atan2((double)T->s, (double)T->c);    /* model: rotation() = the linear part, atan2f correctly rounded */
   if (g_hooks.init_p) { float t4[4] = {T->c, T->s, T->tx, T->ty}; g_hooks.init_p(t4, p); }
 }
 

@@ -56,3 +56,26 @@ def test_short_fp64_sincos_is_within_one_ulp_and_rounds_to_the_same_floats(tmp_p
     twin = open(os.path.join(ROOT, "tests", "sincos_small_twin.c")).read()
     for c in ("1.66666666666666324348e-01", "1.58969099521155010221e-10", "1.13596475577881948265e-11", "0x1.1a62633145c07p-54"):
         assert c in dev and c in twin
+
+
+def _glibc_before_241():
+    import platform
+    lib, ver = platform.libc_ver()
+    try:
+        major, minor = (int(v) for v in ver.split(".")[:2])
+    except ValueError:
+        return False
+    return lib == "glibc" and (major, minor) < (2, 41)          # (2.41 switched these to correctly rounded CORE-MATH code)
+
+
+@pytest.mark.skipif(not _glibc_before_241(), reason="the restatement is the fdlibm-style float atanf / atan2f of glibc < 2.41")
+def test_atan2f_twin_equals_libm(tmp_path):
+    exe = str(tmp_path / "at")
+    subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", os.path.join(ROOT, "tests", "atan2f_twin.c"), "-o", exe, "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout
+    assert "atanf mismatches (every 3rd float): 0" in out.stdout and "atan2f mismatches: 0 of" in out.stdout, out.stdout
+    dev = open(os.path.join(ROOT, "ndt_slam_amd", "csrc", "ndt_libm_f32.hip.h")).read()
+    twin = open(os.path.join(ROOT, "tests", "atan2f_twin.c")).read()
+    for c in ("4.6364760399e-01f", "3.3333334327e-01f", "1.6285819933e-02f", "-8.7422776573e-08f", "7.5497894159e-08f"):
+        assert c in dev and c in twin, c
