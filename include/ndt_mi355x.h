@@ -342,6 +342,14 @@ int ndt_ctx_wait_launch(ndt_ctx *ctx, int back, void *stream);
  * recent call of each kind, measured around the kernel launches only). */
 int ndt_last_timing(const ndt_ctx *ctx, float *map_build_ms, float *align_ms);
 
+/* Self-test of the device's float32 routines (ndt_params::libm_f32 = 1; ndt_slam_amd/csrc/ndt_libm_f32.hip.h): for n yaws
+ * (host array, float32) the device's restatements of glibc's cosf / sinf and of the initial yaw computeTransformation reads
+ * back from the guess matrix -- Eigen's Affine3f.rotation().eulerAngles(0,1,2)[2] with glibc's atan2f, from the cos / sin
+ * just computed (src/PoseEstimator.cpp:22-24 -> the prologue of ndt.align, :28).  A caller on another platform checks them
+ * against its own libm with this before trusting bit-level parity (tests/test_gpu_parity.py does, on 2e6 yaws).
+ * Any output pointer may be NULL. */
+int ndt_selftest_libm_f32(ndt_ctx *ctx, const float *yaw_host, size_t n, float *cos_out, float *sin_out, float *init_yaw_out);
+
 #ifdef __cplusplus
 }
 #endif

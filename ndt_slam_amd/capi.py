@@ -62,6 +62,7 @@ EXPORTS = [
     "ndt_fuse_default_params", "ndt_predict_batch_dev", "ndt_fuse_batch_dev",
     "ndt_remove_neighbors", "ndt_remove_neighbors_dev",
     "ndt_difference_extraction", "ndt_difference_extraction_dev", "ndt_make_map", "ndt_make_map_dev",
+    "ndt_selftest_libm_f32",
 ]
 
 
@@ -100,6 +101,7 @@ def lib():
     L.ndt_eval_at.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp, vp, vp]
     L.ndt_fitness_at.argtypes = [vp, vp, vp, sz, sz, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     L.ndt_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.ndt_selftest_libm_f32.argtypes = [vp, vp, C.c_size_t, vp, vp, vp]
     L.ndt_kernel_timing.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.ndt_launch_interval.argtypes = [vp, i, C.POINTER(C.c_float)]
     L.ndt_align_batch_sharded.argtypes = [vp, vp, i, vp, vp, i, i, vp, vp]
@@ -276,6 +278,14 @@ class Context:
         self.check(lib().ndt_fuse_batch_dev(self.h, results_ptr, pred_ptr, motion_ptr, last_pose_ptr, last_cov_ptr, B,
                                             C.byref(prm), fused_ptr, cov_ptr, successful_ptr, stream),
                    "ndt_fuse_batch_dev")
+
+    def selftest_libm_f32(self, yaws):
+        """Device cosf / sinf / initial yaw (ndt_libm_f32.hip.h) for an array of float32 yaws -> (cos, sin, init_yaw)."""
+        y = np.ascontiguousarray(yaws, dtype=np.float32).ravel()
+        c, s, y0 = np.zeros_like(y), np.zeros_like(y), np.zeros_like(y)
+        self.check(lib().ndt_selftest_libm_f32(self.h, y.ctypes.data, len(y), c.ctypes.data, s.ctypes.data, y0.ctypes.data),
+                   "ndt_selftest_libm_f32")
+        return c, s, y0
 
     def last_timing(self):
         a, b = C.c_float(), C.c_float()

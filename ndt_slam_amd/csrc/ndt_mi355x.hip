@@ -992,6 +992,38 @@ int ndt_align_batch_sharded(ndt_ctx *const *ctxs, const ndt_map *const *maps, in
   return rc_first;
 }
 
+namespace {
+__global__ void __launch_bounds__(256)
+selftest_libm_f32_kernel(const float *__restrict__ yaw, size_t n, float *__restrict__ c, float *__restrict__ s, float *__restrict__ y0) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float cc = sincosf_glibc(yaw[i], 1), ss = sincosf_glibc(yaw[i], 0);
+    if (c) c[i] = cc;
+    if (s) s[i] = ss;
+    if (y0) y0[i] = eigen_init_yaw(cc, ss);
+  }
+}
+}  // namespace
+
+int ndt_selftest_libm_f32(ndt_ctx *ctx, const float *yaw, size_t n, float *cos_out, float *sin_out, float *init_yaw_out) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!yaw || n == 0) return fail(ctx, NDT_E_ARG, "ndt_selftest_libm_f32: bad arguments");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  float *d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&d, 4 * n * sizeof(float)));
+  hipError_t e = hipMemcpyAsync(d, yaw, n * sizeof(float), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) {
+    selftest_libm_f32_kernel<<<grid_for(n, 256), 256, 0, ctx->stream>>>(d, n, d + n, d + 2 * n, d + 3 * n);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess && cos_out) e = hipMemcpyAsync(cos_out, d + n, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && sin_out) e = hipMemcpyAsync(sin_out, d + 2 * n, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess && init_yaw_out) e = hipMemcpyAsync(init_yaw_out, d + 3 * n, n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  hipError_t e2 = hipFree(d); (void)e2;
+  if (e != hipSuccess) return fail(ctx, NDT_E_HIP, std::string("ndt_selftest_libm_f32: ") + hipGetErrorString(e));
+  return NDT_OK;
+}
+
 int ndt_align(ndt_ctx *ctx, const ndt_map *map, const float *scan, size_t n, size_t stride,
               const double init[3], ndt_result *out) {
   if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
