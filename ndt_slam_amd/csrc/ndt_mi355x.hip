@@ -26,6 +26,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <mutex>
 #include <set>
 #include <utility>
 #include <vector>
@@ -130,6 +131,7 @@ struct ndt_map {
 namespace {
 
 std::set<ndt_ctx *> g_live_ctx;                // contexts that exist (a map may outlive a context that only READ it)
+std::mutex g_live_mu;                          // (contexts may be created / destroyed from different host threads)
 
 int fail(ndt_ctx *ctx, int code, const std::string &msg) {
   g_last_error = msg;
@@ -382,7 +384,7 @@ int ndt_ctx_create(int device, ndt_ctx **out) {
   if (!c) return NDT_E_NOMEM;
   const int rc = ctx_init(c, device);
   if (rc) { ndt_ctx_destroy(c); return rc; }      // (the error text stays in ndt_last_error(NULL))
-  g_live_ctx.insert(c);
+  { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.insert(c); }
   *out = c;
   return NDT_OK;
 }
@@ -402,7 +404,7 @@ int ndt_ctx_set_option(ndt_ctx *c, int option, long long value) {
 
 int ndt_ctx_destroy(ndt_ctx *c) {
   if (!c) return NDT_E_ARG;
-  g_live_ctx.erase(c);
+  { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.erase(c); }
   hipError_t e;
   e = hipSetDevice(c->device);
   if (c->stream) e = hipStreamSynchronize(c->stream);
@@ -644,7 +646,8 @@ static int build_end(ndt_ctx *ctx, ndt_map *m) {
       // for the last of them on every context that issued any (the event on that launch's last kernel)
       for (auto &r : m->readers) {
         ndt_ctx *rc_ = r.first;
-        if (!g_live_ctx.count(rc_) || rc_->launches <= r.second || rc_->launches - 1 - r.second >= (unsigned long long)ndt_ctx::kTimeRing) continue;
+        bool alive; { std::lock_guard<std::mutex> lk(g_live_mu); alive = g_live_ctx.count(rc_) != 0; }
+        if (!alive || rc_->launches <= r.second || rc_->launches - 1 - r.second >= (unsigned long long)ndt_ctx::kTimeRing) continue;
         hipEvent_t *evr = rc_->ev_ring + 3 * (r.second % ndt_ctx::kTimeRing);
         HIP_TRY(ctx, hipStreamWaitEvent(st, evr[2], 0));
       }
