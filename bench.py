@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--no-scatter", action="store_true", help="N > 1: every rank generates its own shard instead of receiving it from rank 0")
     ap.add_argument("--map-from-rank0", action="store_true", help="N > 1: only rank 0 generates the target cloud, the others build their map from shard.broadcast_map's copy (by default every rank generates it AND the broadcast is timed and checked against it: comm.broadcast_map_ms)")
     ap.add_argument("--moving-steps", type=int, default=48, help="steps of the moving-local-map side leg (0: skip)")
+    ap.add_argument("--moving-margin", type=int, default=8, help="ndt_params::grid_margin of the second moving-local-map leg (voxels)")
     ap.add_argument("--moving-every", type=int, default=8, help="moving-local-map leg: the cloud's voxel bounding box moves every k-th step")
     ap.add_argument("--steady-steps", type=int, default=200, help="steps of the steady-state side figure (0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -281,7 +282,7 @@ def main():
 
     nst = args.steps + args.warmup
     side_legs = world == 1 and not args.no_single_scan and not c5      # steady-state and moving-map legs behind the timed region
-    n_extra = (max(0, args.steady_steps) + max(0, args.moving_steps)) if side_legs else 0
+    n_extra = (max(0, args.steady_steps) + 2 * max(0, args.moving_steps)) if side_legs else 0
     ev_a = [torch.cuda.Event(enable_timing=args.time_builds) for _ in range(2 * (nst + n_extra))]
     ev_m = [torch.cuda.Event(enable_timing=args.time_builds) for _ in range(2 * (nst + n_extra))]
     stats = {"rebuilt_steps": 0}
@@ -343,8 +344,6 @@ def main():
                     comm["argmax_error"] = "%s: %s" % (type(e).__name__, e)
                 ev_done[i % nbuf].record(side)
 
-    dbg_t = []                                             # NDT_BENCH_DEBUG: host time of the calls of a step
-
     def settle_build():
         """Collect the verdict on the grid the open rebuild was queued with.  NDT_REBUILT: the cloud's voxel bounding box
         had moved (the common case for the reference's sliding local map, src/PointCloudMap.cpp:119-131) -- the library has
@@ -352,14 +351,10 @@ def main():
         again here: the step costs one more build and one more launch."""
         if open_build:
             gm, j = open_build.pop()
-            ta = time.perf_counter()
             stale = gm.rebuild_end()
-            dbg_t.append(("end", time.perf_counter() - ta))
             if stale:
                 stats["rebuilt_steps"] += 1
-                ta = time.perf_counter()
                 launch(j)
-                dbg_t.append(("relaunch", time.perf_counter() - ta))
 
     def step(i):
         gm = gmaps[i % nbuf]
@@ -373,15 +368,11 @@ def main():
         # build and the host goes on -- it collects the verdict on that grid one step later, so the GPU never waits for
         # the host's wake-up from the bounding-box read-back (a plain rebuild blocks right here in every step)
         settle_build()
-        ta = time.perf_counter()
         gm.rebuild_begin(cloud_of[0](i).data_ptr(), len(map_xy), 8)
-        dbg_t.append(("begin", time.perf_counter() - ta))
         open_build.append((gm, i))
         if args.time_builds:
             ev_m[2 * i + 1].record(bstream)
-        ta = time.perf_counter()
         launch(i)
-        dbg_t.append(("launch", time.perf_counter() - ta))
 
     for i in range(args.warmup):
         step(i)
@@ -445,49 +436,54 @@ def main():
         legs["steady_state"] = {"steps": args.steady_steps, "ms_per_step": 1e3 * el / args.steady_steps,
                                 "value": B * args.steady_steps / el,
                                 "note": "the timed loop continued for this many more steps (clock ramped, queues warm)"}
-    if side_legs and args.moving_steps > 0:
+    def moving_leg(first_i, margin):
+        """`--moving-steps` steps over two clouds that take turns every `--moving-every` steps; ndt_params::grid_margin = margin."""
         # cloud B = the cloud with ONE point moved a voxel beyond the bounding box's lower corner: the grid's origin moves by a
         # voxel in x and y (every voxel index changes), the matches stay what they were
         mv = map_xy.copy()
         mv[0] = map_xy.min(axis=0) - np.float32(cfg["resolution"])
         d_map_b = torch.from_numpy(mv).to(dev)
         clouds = [d_map, d_map_b]
-        base_i, k_mv = nxt, max(1, args.moving_every)
-        cloud_of[0] = lambda i: clouds[((i - base_i) // k_mv) % 2]
+        k_mv = max(1, args.moving_every)
+        pm = capi.Params.from_buffer_copy(prm)
+        pm.grid_margin = margin
+        for g in gmaps:
+            g.params = pm
+        cloud_of[0] = lambda i: clouds[((i - first_i) // k_mv) % 2]
         before = stats["rebuilt_steps"]
         fence()
         t0 = time.perf_counter()
-        for i in range(nxt, nxt + args.moving_steps):
-            if os.environ.get("NDT_BENCH_DEBUG"):
-                tq = time.perf_counter(); rb = stats["rebuilt_steps"]
-                step(i)
-                tq1 = time.perf_counter()
-                if os.environ.get("NDT_BENCH_DEBUG") == "2":
-                    torch.cuda.synchronize()
-                print("moving step %d: host %.3f ms, +sync %.3f ms, rebuilt %d" % (i - nxt, (tq1 - tq) * 1e3, (time.perf_counter() - tq) * 1e3, stats["rebuilt_steps"] - rb),
-                      " ".join("%s %.3f" % (k, v * 1e3) for k, v in dbg_t[-5:]), file=sys.stderr)
-                del dbg_t[:]
-                continue
+        for i in range(first_i, first_i + args.moving_steps):
             step(i)
         settle_build()
         fence()
         el = time.perf_counter() - t0
-        last_i = nxt + args.moving_steps - 1
-        nxt += args.moving_steps
+        last_i = first_i + args.moving_steps - 1
         got_mv = d_res2[last_i % nbuf].cpu().numpy().tobytes()
-        fresh = capi.Map(ctx, params=prm, dev_ptr=cloud_of[0](last_i).data_ptr(), n=len(map_xy), stride=8)   # a build from scratch
+        fresh = capi.Map(ctx, params=prm, dev_ptr=cloud_of[0](last_i).data_ptr(), n=len(map_xy), stride=8)   # a build from scratch, exact grid
         chk = torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
         fresh.align_batch_dev(d_scans.data_ptr(), d_off.data_ptr(), B, total_points, d_init.data_ptr(), chk.data_ptr(),
                               shared_scan=c5, stream=stream.cuda_stream)
         torch.cuda.synchronize()
-        legs["moving_map"] = {"steps": args.moving_steps, "box_moves_every": k_mv,
-                              "rebuilt_steps": stats["rebuilt_steps"] - before,
-                              "ms_per_step_moving": 1e3 * el / args.moving_steps, "value_moving": B * args.moving_steps / el,
-                              "identical_to_a_fresh_build": bool(chk.cpu().numpy().tobytes() == got_mv),
-                              "note": "two map buffers, each speculating on the grid of ITS last build: a move of the box costs "
-                                      "one extra build + one repeated launch on each of them"}
+        leg = {"steps": args.moving_steps, "box_moves_every": k_mv, "grid_margin": margin,
+               "rebuilt_steps": stats["rebuilt_steps"] - before,
+               "ms_per_step_moving": 1e3 * el / args.moving_steps, "value_moving": B * args.moving_steps / el,
+               "identical_to_a_fresh_build": bool(chk.cpu().numpy().tobytes() == got_mv)}
         fresh.close()
         cloud_of[0] = lambda i: d_map
+        for g in gmaps:
+            g.params = prm
+        return leg
+
+    if side_legs and args.moving_steps > 0:
+        legs["moving_map"] = moving_leg(nxt, 0)
+        legs["moving_map"]["note"] = ("two map buffers, each speculating on the grid of ITS last build: a move of the box costs "
+                                      "one extra build + one repeated launch on each of them")
+        nxt += args.moving_steps
+        legs["moving_map_margin"] = moving_leg(nxt, args.moving_margin)
+        legs["moving_map_margin"]["note"] = ("ndt_params::grid_margin = %d voxels: the grid queued ahead stays good while the box "
+                                             "moves inside the margin (same records; include/ndt_mi355x.h)" % args.moving_margin)
+        nxt += args.moving_steps
 
     out = None
     if rank == 0:

@@ -66,6 +66,17 @@ typedef struct ndt_params {
                                   operation for operation and equal to libm on all 2.2e9 floats |x| < 120
                                   (tests/test_libm_f32.py); 0: correctly rounded (differs from glibc by one ulp in 1.3 % of
                                   the angles).  asinf / acosf / atan2f stay modelled as correctly rounded: DESIGN.md 2 */
+  int    grid_margin;       /* 0 (every preset): the voxel grid is the one PCL's VoxelGridCovariance derives from the cloud's
+                               bounding box, and a rebuild whose box has moved by a voxel is queued twice (NDT_REBUILT).
+                               m > 0: a grid built or re-queued for this map is that box widened by m voxels on every side,
+                               and ndt_map_rebuild_end accepts the grid queued ahead as long as it still contains the
+                               cloud's box and is at most 2 m voxels wider on any side -- a sliding local map
+                               (src/PointCloudMap.cpp:119-131) then pays the second build once per ~m voxels of travel
+                               instead of once per voxel.  Matches, fitness scores and ndt_eval_at do not depend on it,
+                               to the last bit (same voxels, same statistics, same order of every sum:
+                               tests/test_gpu_parity.py) -- except a match flagged NDT_FLAG_REGION_CLIPPED, whose window is
+                               cut to the grid first (the order of its sums may then differ); ndt_map_info and
+                               ndt_map_export describe the widened grid */
 } ndt_params;
 
 /* Result of one scan-to-map match = everything src/PoseEstimator.cpp:28-64 reads back from

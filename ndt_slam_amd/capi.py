@@ -27,7 +27,7 @@ class Params(C.Structure):
         ("eig_mult", C.c_double), ("cov_unbiased", C.c_int), ("cov_init_identity", C.c_int),
         ("conv_ge", C.c_int), ("radius_inclusive", C.c_int), ("transform_sse", C.c_int),
         ("stale_h_ang", C.c_int), ("snap_thresh", C.c_double), ("mt_max_iter", C.c_int),
-        ("mt_mu", C.c_double), ("mt_nu", C.c_double), ("libm_f32", C.c_int),
+        ("mt_mu", C.c_double), ("mt_nu", C.c_double), ("libm_f32", C.c_int), ("grid_margin", C.c_int),
     ]
 
 

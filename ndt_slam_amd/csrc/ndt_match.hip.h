@@ -222,16 +222,21 @@ __device__ __forceinline__ void region_from_bbox(const MapView &M, Lds &L) {
     Region r = {0, 0, 0, 0, 0, 0};
     L.clipped = 0;
     if (L.sbox[0] <= L.sbox[2]) {
-      // clip the bbox to the padded map grid, add the slack, then fit the slot-table budget around
-      // the bbox centre
+      // The bbox plus the slack, wherever it lies: cells outside the map's grid are simply empty (fill_window), and a window
+      // that does not depend on the grid's extent keeps the order of the scan copy -- hence every sum, to the last bit --
+      // independent of it (ndt_params::grid_margin widens the grid; round 4).  Only a bbox too large for the slot table
+      // is cut down: first to the padded grid, then around its centre (flagged: NDT_FLAG_REGION_CLIPPED).
       long long x0 = (long long)L.sbox[0] - kRegionMargin, x1 = (long long)L.sbox[2] + kRegionMargin;
       long long y0 = (long long)L.sbox[1] - kRegionMargin, y1 = (long long)L.sbox[3] + kRegionMargin;
-      x0 = x0 < -2 ? -2 : x0; y0 = y0 < -2 ? -2 : y0;
-      x1 = x1 > M.div_x + 1 ? M.div_x + 1 : x1; y1 = y1 > M.div_y + 1 ? M.div_y + 1 : y1;
       long long w = x1 - x0 + 1, h = y1 - y0 + 1;
+      if (w * h > kRegionCells) {
+        L.clipped = 1;
+        x0 = x0 < -2 ? -2 : x0; y0 = y0 < -2 ? -2 : y0;
+        x1 = x1 > M.div_x + 1 ? M.div_x + 1 : x1; y1 = y1 > M.div_y + 1 ? M.div_y + 1 : y1;
+        w = x1 - x0 + 1; h = y1 - y0 + 1;
+      }
       if (w > 0 && h > 0) {
         if (w * h > kRegionCells) {
-          L.clipped = 1;
           long long w2 = w > 128 ? 128 : w;
           long long h2 = kRegionCells / w2; if (h2 > h) h2 = h;
           x0 += (w - w2) / 2; y0 += (h - h2) / 2; w = w2; h = h2;

@@ -316,7 +316,7 @@ static void params_common(ndt_params *p) {
   p->resolution = 1.0f; p->step_size = 0.1; p->trans_eps = 0.01; p->max_iter = 35;   // PoseEstimator.h:63-64
   p->outlier_ratio = 0.55; p->min_pts = 6; p->eig_mult = 0.01;
   p->conv_ge = 0; p->radius_inclusive = 0; p->stale_h_ang = 0;
-  p->snap_thresh = 10e-5; p->mt_max_iter = 10; p->mt_mu = 1.e-4; p->mt_nu = 0.9;
+  p->snap_thresh = 10e-5; p->mt_max_iter = 10; p->mt_mu = 1.e-4; p->mt_nu = 0.9; p->grid_margin = 0;
 }
 
 int ndt_params_pcl110(ndt_params *p) {      // PCL 1.9 / 1.10: Leaf() starts cov_ at the identity, biased
@@ -635,10 +635,22 @@ static int build_end(ndt_ctx *ctx, ndt_map *m) {
   G.min_bx = (int)floorf(mnx * inv_leaf); G.min_by = (int)floorf(mny * inv_leaf);
   long long dx = (long long)(int)floorf(mxx * inv_leaf) - G.min_bx + 1;
   long long dy = (long long)(int)floorf(mxy * inv_leaf) - G.min_by + 1;
-  if (dx * dy > (1LL << 28)) return fail(ctx, NDT_E_GRID, "ndt_map_build: voxel grid larger than 2^28 cells");
-  G.div_x = (int)dx; G.div_y = (int)dy; G.gw = G.div_x + 4; G.gh = G.div_y + 4;
-  const bool same = m->pend_queued && G.min_bx == m->grid.min_bx && G.min_by == m->grid.min_by &&
-                    G.div_x == m->grid.div_x && G.div_y == m->grid.div_y;
+  // ndt_params::grid_margin: the grid queued ahead is good if it contains the cloud's box and is not much wider
+  const int mg = prm->grid_margin > 0 ? (prm->grid_margin < 4096 ? prm->grid_margin : 4096) : 0;
+  bool same = false;
+  if (m->pend_queued) {
+    const GridDims &S = m->grid;
+    const long long lo_x = (long long)G.min_bx - S.min_bx, lo_y = (long long)G.min_by - S.min_by;       // slack on the low sides
+    const long long hi_x = ((long long)S.min_bx + S.div_x) - ((long long)G.min_bx + dx);
+    const long long hi_y = ((long long)S.min_by + S.div_y) - ((long long)G.min_by + dy);
+    same = lo_x >= 0 && lo_y >= 0 && hi_x >= 0 && hi_y >= 0 && lo_x <= 2 * mg && lo_y <= 2 * mg && hi_x <= 2 * mg && hi_y <= 2 * mg;
+  }
+  if (same) G = m->grid;
+  else {
+    G.min_bx -= mg; G.min_by -= mg; dx += 2 * mg; dy += 2 * mg;
+    if (dx * dy > (1LL << 28)) return fail(ctx, NDT_E_GRID, "ndt_map_build: voxel grid larger than 2^28 cells");
+    G.div_x = (int)dx; G.div_y = (int)dy; G.gw = G.div_x + 4; G.gh = G.div_y + 4;
+  }
   int redone = 0;
   if (!same) {
     if (m->pend_queued) {

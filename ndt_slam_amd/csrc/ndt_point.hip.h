@@ -134,8 +134,8 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
   const float fx = fminf(fmaxf(floorf(xt * M.inv_leaf), -1.0e9f), 1.0e9f);     // (NaN -> -1e9: outside every window and grid)
   const float fy = fminf(fmaxf(floorf(yt * M.inv_leaf), -1.0e9f), 1.0e9f);
   const Region &R = W.R;
-  // window coordinates.  The window lies inside the padded grid (compute_region clips it), so "3x3 neighbourhood inside
-  // the window" implies "inside the grid" and "finite": one unsigned comparison per axis decides the fast path.
+  // window coordinates.  Window cells outside the map's grid carry the "outside the search set" slot (fill_window) and a
+  // non-finite point lands at -1e9, outside every window: one unsigned comparison per axis decides the fast path.
   const int lx = (int)fx - (M.min_bx + R.x0), ly = (int)fy - (M.min_by + R.y0);
   const bool inwin = ((unsigned)(lx - 1) < (unsigned)max(R.rw - 2, 0)) & ((unsigned)(ly - 1) < (unsigned)max(R.rh - 2, 0));
   // LDS probes with clamped indices (results dropped when !inwin)

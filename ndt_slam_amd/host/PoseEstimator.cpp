@@ -26,6 +26,7 @@ PoseEstimator::PoseEstimator(int device, double coeNDTCov, double Transformation
   prm_.step_size = StepSize;                  // ndt.setStepSize               :79
   prm_.resolution = (float)Resolution;        // ndt.setResolution             :81
   prm_.max_iter = MaximumIterations;          // ndt.setMaximumIterations      :83
+  prm_.grid_margin = 8;                       // sliding local map: the voxel grid keeps 8 voxels to spare (ndt_mi355x.h)
   std::memset(&last_, 0, sizeof(last_));
   if (ndt_ctx_create(device, &ctx_) != NDT_OK) ctx_ = nullptr;     // no GPU: estimatePose reports 1e7
 }

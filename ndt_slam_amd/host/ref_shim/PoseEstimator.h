@@ -46,6 +46,8 @@ class PoseEstimator {
     prm.step_size  = StepSize;
     prm.resolution = (float)Resolution;
     prm.max_iter   = MaximumIterations;
+    prm.grid_margin = 8;                            // the local map slides (src/PointCloudMap.cpp:119-131): a voxel grid with
+                                                    // 8 voxels to spare is rebuilt in place until the box has moved that far
     int device = 0;
     ros::param::get("ndt_device", device);          // one process per GPU
     if (ndt_ctx_create(device, &ctx) != NDT_OK) {

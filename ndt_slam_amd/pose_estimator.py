@@ -110,7 +110,7 @@ class PoseEstimator:
         self.LeafSize = LeafSize
         self.params = capi.default_params(resolution=Resolution, step_size=StepSize,
                                           trans_eps=TransformationEpsilon, max_iter=MaximumIterations,
-                                          **switches)
+                                          **dict(dict(grid_margin=8), **switches))   # sliding local map: 8 voxels to spare
         self.totalError = 0.0          # PoseEstimator.h:58 (never written by the reference either)
         self.source_cloud = None
         self.target_cloud = None

@@ -43,6 +43,7 @@ static void params_common(ndt_oracle_params *p) {
   p->mt_max_iter = 10;
   p->mt_mu = 1.e-4;
   p->mt_nu = 0.9;
+  p->grid_margin = 0;
 }
 
 /* Presets of the version-sensitive switches.  preset 0 = PCL 1.9/1.10 (the default: the

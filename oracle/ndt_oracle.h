@@ -58,6 +58,8 @@ typedef struct ndt_oracle_params {
   double mt_nu;             /* (11) 0.9                                                        */
   int    libm_f32;          /* (12b) float32 cos / sin of a trial's yaw: 1: THIS machine's libm cosf / sinf (glibc:
                                      the reference's platform; what Eigen's AngleAxisf calls); 0: correctly rounded */
+  int    grid_margin;       /* layout only (the struct is shared with ndt_params): the checker's voxel grid is always the
+                                     one PCL derives from the cloud's bounding box */
 } ndt_oracle_params;
 
 /* Result of one match.  Layout shared with include/ndt_mi355x.h's ndt_result. */

@@ -44,6 +44,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     mv = d["moving_map"]
     assert mv["steps"] == 48 and mv["box_moves_every"] == 8 and mv["rebuilt_steps"] == 2 * (48 // 8 - 1)
     assert mv["identical_to_a_fresh_build"] is True and 0 < mv["ms_per_step_moving"] < 3 * d["ms_per_step"]
+    # ... and with ndt_params::grid_margin the grid queued ahead survives the move: same records, (almost) no repeated builds
+    mm = d["moving_map_margin"]
+    assert mm["grid_margin"] == 8 and mm["rebuilt_steps"] <= 2 and mm["identical_to_a_fresh_build"] is True
+    assert 0 < mm["ms_per_step_moving"] < mv["ms_per_step_moving"]
     assert d["steady_state"]["steps"] == 200 and d["steady_state"]["value"] > 0
 
 

@@ -205,6 +205,76 @@ def test_requeued_build_waits_for_the_launches_that_read_the_stale_tables(gpu):
     gm.close(); bctx.close(); mctx.close()
 
 
+def test_grid_margin_widens_the_grid_and_changes_nothing_else(gpu, c1_world):
+    """ndt_params::grid_margin = m: the voxel grid is the cloud's box widened by m voxels -- the same voxels with the same
+    statistics at other indices, byte-identical matches / evaluations / fitness scores -- and a two-phase rebuild keeps the
+    grid it queued ahead while the box moves inside the margin (the reference's sliding local map,
+    src/PointCloudMap.cpp:119-131): the verdicts of ndt_map_rebuild_end follow the rule in include/ndt_mi355x.h, and every
+    step's records equal those of an exact-grid build from scratch."""
+    import torch
+    capi, ctx = gpu
+    m, sf, cfg = c1_world
+    res, mg = cfg["resolution"], 5
+    p0 = capi.default_params(resolution=res)
+    pm = capi.default_params(resolution=res, grid_margin=mg)
+    assert p0.grid_margin == 0
+    g0, gw = capi.Map(ctx, m, p0), capi.Map(ctx, m, pm)
+    i0, iw = g0.info(), gw.info()
+    assert (iw.min_bx, iw.min_by, iw.div_x, iw.div_y) == (i0.min_bx - mg, i0.min_by - mg, i0.div_x + 2 * mg, i0.div_y + 2 * mg)
+    assert iw.n_valid == i0.n_valid and iw.n_cells == i0.n_cells
+
+    def voxels(e, i):
+        return np.stack([e["idx"] % i.div_x + i.min_bx, e["idx"] // i.div_x + i.min_by], 1)
+
+    e0, ew = g0.export(), gw.export()
+    assert np.array_equal(voxels(e0, i0), voxels(ew, iw))
+    for k in ("npts", "cent", "mean", "icov"):
+        assert e0[k].tobytes() == ew[k].tobytes(), k
+    scans, off, truths, inits = sf.batch(0, 12)
+    assert g0.align_batch(scans, off, inits).tobytes() == gw.align_batch(scans, off, inits).tobytes()
+    one = scans[int(off[3]):int(off[4])]
+    for p in (truths[3], inits[3]):
+        a, b = g0.eval_at(one, p), gw.eval_at(one, p)
+        assert (a[0], a[1].tobytes(), a[2].tobytes(), a[3]) == (b[0], b[1].tobytes(), b[2].tobytes(), b[3])
+    c, s_ = math.cos(truths[3][2]), math.sin(truths[3][2])
+    assert g0.fitness_at(one, c, s_, truths[3][0], truths[3][1]) == gw.fitness_at(one, c, s_, truths[3][0], truths[3][1])
+
+    # the box slides a voxel per step: up and to the left
+    S = (iw.min_bx, iw.min_by, iw.div_x, iw.div_y)
+    verdicts = []
+    for k in range(1, 9):
+        shift = np.array([k * res, -k * res], np.float32)
+        moved = (m + shift).astype(np.float32)
+        d = torch.from_numpy(moved).cuda()
+        torch.cuda.synchronize()
+        gw.rebuild_begin(d.data_ptr(), len(moved), 8)
+        stale = gw.rebuild_end()
+        fresh = capi.Map(ctx, moved, p0)
+        E = fresh.info()
+        lo_x, lo_y = E.min_bx - S[0], E.min_by - S[1]
+        hi_x, hi_y = (S[0] + S[2]) - (E.min_bx + E.div_x), (S[1] + S[3]) - (E.min_by + E.div_y)
+        keep = all(0 <= v <= 2 * mg for v in (lo_x, lo_y, hi_x, hi_y))
+        assert stale == (not keep), (k, lo_x, lo_y, hi_x, hi_y)
+        if not keep:
+            S = (E.min_bx - mg, E.min_by - mg, E.div_x + 2 * mg, E.div_y + 2 * mg)
+        gi = gw.info()
+        assert (gi.min_bx, gi.min_by, gi.div_x, gi.div_y) == S and gi.n_valid == E.n_valid
+        verdicts.append(stale)
+        ini = inits + np.array([shift[0], shift[1], 0.0])
+        assert gw.align_batch(scans, off, ini).tobytes() == fresh.align_batch(scans, off, ini).tobytes(), k
+        fresh.close()
+    assert verdicts.count(True) == 1 and not verdicts[0]          # eight voxels of travel, one repeated build
+    # a smaller margin than the grid was built with: the wide grid is refused, the next one is exact again
+    gw.params = p0
+    d = torch.from_numpy(m).cuda()
+    torch.cuda.synchronize()
+    gw.rebuild_begin(d.data_ptr(), len(m), 8)
+    assert gw.rebuild_end() is True
+    gi = gw.info()
+    assert (gi.min_bx, gi.min_by, gi.div_x, gi.div_y) == (i0.min_bx, i0.min_by, i0.div_x, i0.div_y)
+    g0.close(); gw.close()
+
+
 def test_map_destroy_closes_an_open_rebuild(gpu, c1_world):
     """ndt_map_destroy on a map with an open ndt_map_rebuild_begin: the context must be usable afterwards."""
     import torch
