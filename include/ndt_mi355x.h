@@ -73,9 +73,8 @@ typedef struct ndt_params {
                                cloud's box and is at most 2 m voxels wider on any side -- a sliding local map
                                (src/PointCloudMap.cpp:119-131) then pays the second build once per ~m voxels of travel
                                instead of once per voxel.  Matches, fitness scores and ndt_eval_at do not depend on it,
-                               to the last bit (same voxels, same statistics, same order of every sum:
-                               tests/test_gpu_parity.py) -- except a match flagged NDT_FLAG_REGION_CLIPPED, whose window is
-                               cut to the grid first (the order of its sums may then differ); ndt_map_info and
+                               to the last bit (same voxels, same statistics, and the order of every sum follows the scan
+                               and the pose, never the grid's extent: tests/test_gpu_parity.py); ndt_map_info and
                                ndt_map_export describe the widened grid */
 } ndt_params;
 

@@ -217,30 +217,33 @@ __device__ __forceinline__ Window window_of(const Region &R, const uint4 *pool) 
 }
 
 // thread 0: window geometry from the bounding box of the scan's voxel coordinates (L.sbox) -> L.RG, L.clipped
-__device__ __forceinline__ void region_from_bbox(const MapView &M, Lds &L) {
+__device__ __forceinline__ void region_from_bbox(const MapView &M, const Tf32 &T0, Lds &L) {
   {
     Region r = {0, 0, 0, 0, 0, 0};
     L.clipped = 0;
     if (L.sbox[0] <= L.sbox[2]) {
       // The bbox plus the slack, wherever it lies: cells outside the map's grid are simply empty (fill_window), and a window
       // that does not depend on the grid's extent keeps the order of the scan copy -- hence every sum, to the last bit --
-      // independent of it (ndt_params::grid_margin widens the grid; round 4).  Only a bbox too large for the slot table
-      // is cut down: first to the padded grid, then around its centre (flagged: NDT_FLAG_REGION_CLIPPED).
+      // independent of it (ndt_params::grid_margin widens the grid; round 4).  A bbox too large for the slot table is cut
+      // down around the SENSOR's voxel (the first pose's translation: the scan surrounds it, whatever a stray far return
+      // does to the bbox), kept inside the bbox; flagged NDT_FLAG_REGION_CLIPPED.
       long long x0 = (long long)L.sbox[0] - kRegionMargin, x1 = (long long)L.sbox[2] + kRegionMargin;
       long long y0 = (long long)L.sbox[1] - kRegionMargin, y1 = (long long)L.sbox[3] + kRegionMargin;
       long long w = x1 - x0 + 1, h = y1 - y0 + 1;
-      if (w * h > kRegionCells) {
-        L.clipped = 1;
-        x0 = x0 < -2 ? -2 : x0; y0 = y0 < -2 ? -2 : y0;
-        x1 = x1 > M.div_x + 1 ? M.div_x + 1 : x1; y1 = y1 > M.div_y + 1 ? M.div_y + 1 : y1;
-        w = x1 - x0 + 1; h = y1 - y0 + 1;
-      }
       if (w > 0 && h > 0) {
         if (w * h > kRegionCells) {
-          long long w2 = w > 128 ? 128 : w;
+          L.clipped = 1;
+          const long long w2 = w > 128 ? 128 : w;
           long long h2 = kRegionCells / w2; if (h2 > h) h2 = h;
-          x0 += (w - w2) / 2; y0 += (h - h2) / 2; w = w2; h = h2;
+          const float sx = fminf(fmaxf(floorf(T0.tx * M.inv_leaf), -1.0e9f), 1.0e9f);    // (NaN -> -1e9, as everywhere)
+          const float sy = fminf(fmaxf(floorf(T0.ty * M.inv_leaf), -1.0e9f), 1.0e9f);
+          long long cx0 = ((long long)(int)sx - M.min_bx) - w2 / 2, cy0 = ((long long)(int)sy - M.min_by) - h2 / 2;
+          cx0 = cx0 < x0 ? x0 : (cx0 > x1 - w2 + 1 ? x1 - w2 + 1 : cx0);
+          cy0 = cy0 < y0 ? y0 : (cy0 > y1 - h2 + 1 ? y1 - h2 + 1 : cy0);
+          x0 = cx0; y0 = cy0; w = w2; h = h2;
         }
+        const long long far = 1ll << 30;          // (a scan of nothing but far-away returns: keep the int arithmetic of the passes in range)
+        x0 = x0 < -far ? -far : (x0 > far ? far : x0); y0 = y0 < -far ? -far : (y0 > far ? far : y0);
         r.x0 = (int)x0; r.y0 = (int)y0; r.rw = (int)w; r.rh = (int)h;
       }
     }
@@ -274,7 +277,7 @@ __device__ __noinline__ void compute_region(const MapView &M, const Tf32 &T0, co
     atomicMin(&L.sbox[0], mnx); atomicMin(&L.sbox[1], mny); atomicMax(&L.sbox[2], mxx); atomicMax(&L.sbox[3], mxy);
   }
   __syncthreads();
-  if (threadIdx.x == 0) region_from_bbox(M, L);
+  if (threadIdx.x == 0) region_from_bbox(M, T0, L);
   __syncthreads();
 }
 
@@ -636,7 +639,7 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) region_from_bbox(M, L);
+  if (threadIdx.x == 0) region_from_bbox(M, L.S.T, L);
   __syncthreads();
   NDT_STAMP(stamps, t0s, 1);
   const Region r = L.RG;
