@@ -95,7 +95,9 @@ __device__ __forceinline__ void wave_runs(int v, int lane, int &head, int &len) 
 }
 
 __global__ void __launch_bounds__(256)
-map_count_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims G, int *__restrict__ count) {
+map_count_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims G, int *__restrict__ count,
+                 int *__restrict__ counters) {
+  if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0;     // the build's small counters (cells, valid, big voxels, scan ticket), for the kernels behind this one
   const int lane = threadIdx.x & 63;
   const size_t nround = (n + 63) / 64 * 64;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < nround; i += (size_t)gridDim.x * blockDim.x) {
@@ -106,109 +108,103 @@ map_count_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDims
   }
 }
 
-// exclusive scan of count[0..ng) into start[0..ng], three small kernels
-constexpr int kScanBlock = 256, kScanPer = 8, kScanTile = kScanBlock * kScanPer;
+// Exclusive scan of count[0..ng) into start[0..ng] in ONE kernel (round 4; before: tile sums | offsets of the tile sums |
+// apply -- three launches for 14 us of work and two launch latencies).  Single pass with decoupled look-back: a workgroup
+// takes its tile number from a ticket (so every tile in front of it has been taken by a workgroup that is running or done:
+// no workgroup waits for one that has not started), adds up its 2048 counters, publishes the sum as an AGGREGATE, looks back
+// over its predecessors' words -- 64 at a time, one per lane of wave 0 -- adding aggregates until it meets an inclusive
+// PREFIX, then publishes its own prefix.  The words validate themselves: value | tag of this build << 32 | kind << 62, written
+// and read as one 64-bit word with agent-scope atomics (cdna_hip_programming.md Guideline 16, R2); words of earlier builds
+// carry other tags and are waited out, so nothing is cleared between builds.  A predecessor publishes its aggregate right
+// after its own loads, before it waits for anything: every wait ends.
+// Two sums travel together -- the points in front of a voxel (its offset) and the voxels with more than kBigVoxel points
+// in front of it (its place in the list of big voxels; an atomic per wave on one counter used to take most of this
+// kernel's time: same-address atomics queue up at ~50 ns each) -- as two words per tile with a look-back each.
+constexpr int kScanBlock = 1024, kScanPer = 8, kScanTile = kScanBlock * kScanPer;
 constexpr int kBigVoxel = 16;        // voxels with more points are handled by a whole wave (order, statistics)
+constexpr unsigned long long kScanAgg = 1ull << 62, kScanPre = 2ull << 62;
 
 __global__ void __launch_bounds__(kScanBlock)
-scan_tile_sums_kernel(const int *__restrict__ in, size_t n, int *__restrict__ tile_sum, int *__restrict__ counters) {
-  __shared__ int sh[kScanBlock / 64];
-  if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0;     // the build's small counters, for the kernels behind this one
-  size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPer;
-  int s = 0;
-#pragma unroll
-  for (int k = 0; k < kScanPer; ++k) if (base + k < n) s += in[base + k];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o);
-  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+scan_onepass_kernel(const int *__restrict__ in, size_t n, unsigned long long *__restrict__ state /* 2 words per tile */, unsigned tag,
+                    int ntiles, int *__restrict__ ticket, int *__restrict__ out /* n + 1 (+ 3 copies; 4 readable ints in front) */,
+                    int *__restrict__ big /* voxels with more than kBigVoxel points, in voxel order */, int *__restrict__ nbig, int big_cap) {
+  __shared__ int sh_s[kScanBlock / 64], sh_b[kScanBlock / 64];
+  __shared__ int s_tile, s_base_s, s_base_b;
+  if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1);
   __syncthreads();
-  if (threadIdx.x == 0) { int t = 0; for (int w = 0; w < kScanBlock / 64; ++w) t += sh[w]; tile_sum[blockIdx.x] = t; }
-}
-
-// Grids of more than kScanDirect tiles (8M voxels; ndt_map_build accepts up to 2^28 = 131072 tiles): every workgroup
-// adding up all tile sums in front of it would be O(ntiles^2) loads, so one workgroup turns the tile sums into exclusive
-// offsets first (in place; tile_sum[ntiles] = the grand total) and scan_apply_kernel reads its offset (`prefixed`).
-constexpr int kScanDirect = 4096;
-__global__ void __launch_bounds__(1024)
-scan_tile_offsets_kernel(int *__restrict__ tile_sum, int ntiles) {
-  __shared__ int sh[1024];
-  const int per = (ntiles + 1023) / 1024;
-  const int t0 = min((int)threadIdx.x * per, ntiles), t1 = min(t0 + per, ntiles);
-  int s = 0;
-  for (int t = t0; t < t1; ++t) s += tile_sum[t];
-  sh[threadIdx.x] = s;
-  __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {
-    const int v = (int)threadIdx.x >= o ? sh[threadIdx.x - o] : 0;
-    __syncthreads();
-    sh[threadIdx.x] += v;
-    __syncthreads();
+  const int tile = s_tile, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t base = (size_t)tile * kScanTile + (size_t)threadIdx.x * kScanPer;
+  int v[kScanPer]; int s = 0; unsigned bigmask = 0;
+#pragma unroll
+  for (int k = 0; k < kScanPer; ++k) {
+    v[k] = (base + k < n) ? in[base + k] : 0;
+    s += v[k];
+    if (v[k] > kBigVoxel) bigmask |= 1u << k;
   }
-  int run = sh[threadIdx.x] - s;
-  for (int t = t0; t < t1; ++t) { const int v = tile_sum[t]; tile_sum[t] = run; run += v; }
-  if (threadIdx.x == 1023) tile_sum[ntiles] = sh[1023];
-}
-
-__global__ void __launch_bounds__(kScanBlock)
-scan_apply_kernel(const int *__restrict__ in, size_t n, const int *__restrict__ tile_sum, int ntiles, int prefixed,
-                  int *__restrict__ out /* n + 1 */,
-                  int *__restrict__ big /* voxels with more than kBigVoxel points */, int *__restrict__ nbig, int big_cap) {
-  __shared__ int sh[kScanBlock];
-  __shared__ int tile_base, grand_total;
-  // offset of this tile = sum of the tile sums in front of it (a few hundred values: every workgroup adds them up
-  // itself -- a scan kernel of one workgroup between two kernels cost a launch latency for 4 us of work)
-  if (prefixed) {
-    if (threadIdx.x == 0) { tile_base = tile_sum[blockIdx.x]; grand_total = tile_sum[ntiles]; }
-    __syncthreads();
-  } else {
-    int before = 0, all = 0;
-    for (int t = threadIdx.x; t < ntiles; t += kScanBlock) { const int v = tile_sum[t]; all += v; if (t < (int)blockIdx.x) before += v; }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { before += __shfl_down(before, o); all += __shfl_down(all, o); }
-    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = before; sh[4 + (threadIdx.x >> 6)] = all; }
-    __syncthreads();
-    if (threadIdx.x == 0) { tile_base = sh[0] + sh[1] + sh[2] + sh[3]; grand_total = sh[4] + sh[5] + sh[6] + sh[7]; }
-    __syncthreads();
-  }
-  size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanPer;
-  int v[kScanPer]; int s = 0;
-#pragma unroll
-  for (int k = 0; k < kScanPer; ++k) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
-  // exclusive prefix of the threads' sums over the block: DPP scan inside a wave, the four wave totals through LDS
-  // (round 4; a Hillis-Steele ladder through LDS with two barriers per step took most of this kernel's 11 us)
-  const int incl_w = (int)wave_incl_scan((unsigned)s);
-  __syncthreads();                               // (sh was used above)
-  if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = incl_w;
+  const int nb = __builtin_popcount(bigmask);
+  const int incl_s = (int)wave_incl_scan((unsigned)s), incl_b = (int)wave_incl_scan((unsigned)nb);
+  if (lane == 63) { sh_s[wave] = incl_s; sh_b[wave] = incl_b; }
   __syncthreads();
-  int before_w = 0;
+  int before_s = 0, total_s = 0, before_b = 0, total_b = 0;
 #pragma unroll
-  for (int w = 0; w < kScanBlock / 64; ++w) before_w += (w < (int)(threadIdx.x >> 6)) ? sh[w] : 0;
-  const int incl_b = before_w + incl_w;
-  int run = tile_base + incl_b - s;
-  unsigned bigmask = 0;
+  for (int w = 0; w < kScanBlock / 64; ++w) {
+    before_s += (w < wave) ? sh_s[w] : 0; total_s += sh_s[w];
+    before_b += (w < wave) ? sh_b[w] : 0; total_b += sh_b[w];
+  }
+  const unsigned long long tagged = (unsigned long long)(tag & 0x3fffffffu) << 32;
+  auto publish = [&](int which, unsigned long long kind, int value) {
+    __hip_atomic_store(&state[2 * (size_t)tile + which], kind | tagged | (unsigned)value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto valid = [&](unsigned long long w) { return ((w ^ tagged) & (0x3fffffffull << 32)) == 0ull && (w >> 62) != 0ull; };
+  if (wave == 0) {
+    if (lane == 0) { publish(0, tile == 0 ? kScanPre : kScanAgg, total_s); publish(1, tile == 0 ? kScanPre : kScanAgg, total_b); }
+    int excl_s = 0, excl_b = 0;
+    bool open_s = true, open_b = true;                                     // (wave-uniform) still looking for a prefix
+    for (int first = tile - 1; first >= 0 && (open_s || open_b); first -= 64) {      // (tile 0: no turn)
+      const int j = first - lane;
+      unsigned long long ws = kScanPre | tagged, wb = kScanPre | tagged;   // in front of tile 0: inclusive prefixes of zero
+      if (j >= 0) {
+        do {
+          ws = __hip_atomic_load(&state[2 * (size_t)j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          wb = __hip_atomic_load(&state[2 * (size_t)j + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while (!valid(ws) || !valid(wb));
+      }
+      if (open_s) {
+        const unsigned long long pre = __ballot((ws >> 62) == 2ull);      // lanes (nearest tile first) that hold a prefix
+        const int stop = pre ? __builtin_ctzll(pre) : 63;                 // add lanes 0 .. stop
+        int part = lane <= stop ? (int)(unsigned)ws : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        excl_s += part;
+        if (pre) open_s = false;
+      }
+      if (open_b) {
+        const unsigned long long pre = __ballot((wb >> 62) == 2ull);
+        const int stop = pre ? __builtin_ctzll(pre) : 63;
+        int part = lane <= stop ? (int)(unsigned)wb : 0;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        excl_b += part;
+        if (pre) open_b = false;
+      }
+    }
+    if (lane == 0) {
+      s_base_s = excl_s; s_base_b = excl_b;
+      if (tile > 0) { publish(0, kScanPre, excl_s + total_s); publish(1, kScanPre, excl_b + total_b); }
+    }
+  }
+  __syncthreads();
+  int run = s_base_s + before_s + incl_s - s;
+  int q0 = s_base_b + before_b + incl_b - nb;
 #pragma unroll
   for (int k = 0; k < kScanPer; ++k) {
     if (base + k < n) out[base + k] = run;
     run += v[k];
-    if (v[k] > kBigVoxel) bigmask |= 1u << k;
+    if ((bigmask >> k) & 1u) { if (q0 < big_cap) big[q0] = (int)(base + k); ++q0; }
   }
-  {                                              // list of the big voxels: one atomic per wave
-    const int mine = __builtin_popcount(bigmask), lane = threadIdx.x & 63;
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
-    const int wave_total = __shfl(incl, 63);
-    int q0 = 0;
-    if (lane == 63 && wave_total > 0) q0 = atomicAdd(nbig, wave_total);
-    q0 = __shfl(q0, 63) + incl - mine;
-#pragma unroll
-    for (int k = 0; k < kScanPer; ++k)
-      if ((bigmask >> k) & 1u) { if (q0 < big_cap) big[q0] = (int)(base + k); ++q0; }
-  }
-  if (blockIdx.x == 0 && threadIdx.x < 4) {
-    out[n + threadIdx.x] = grand_total;          // out[n], + 3 readable copies
-    out[(int)threadIdx.x - 4] = 0;               // the four readable ints in front of out[0] (ndt_fitness.hip.h)
-  }
+  if (tile == ntiles - 1 && threadIdx.x < 4) out[n + threadIdx.x] = s_base_s + total_s;   // out[n], + 3 readable copies
+  if (tile == ntiles - 1 && threadIdx.x == 4) *nbig = s_base_b + total_b;
+  if (tile == 0 && threadIdx.x < 4) out[(int)threadIdx.x - 4] = 0;                        // the four readable ints in front of out[0] (ndt_fitness.hip.h)
 }
 
 __global__ void __launch_bounds__(256)

@@ -107,8 +107,10 @@ struct ndt_map {
   MapView view;
   size_t n = 0, ng = 0, npad = 0;
   // device buffers (grow-only across rebuilds)
-  int *count = nullptr, *start = nullptr, *tile = nullptr, *npts_grid = nullptr;
-  size_t count_cap = 0, start_cap = 0, tile_cap = 0, npts_cap = 0;
+  int *count = nullptr, *start = nullptr, *npts_grid = nullptr;
+  size_t count_cap = 0, start_cap = 0, npts_cap = 0;
+  unsigned long long *scan_state = nullptr; size_t scan_state_cap = 0;   // scan_onepass_kernel: two tagged words per tile
+  unsigned scan_seq = 0;                                                  // tag of the last build's words
   bool count_clean = false;                   // count[0 .. count_cap) is all zero (a complete build leaves it so: the scatter takes back what the count added)
   int *perm = nullptr, *perm_sorted = nullptr; float2 *pts = nullptr;
   size_t perm_cap = 0, perm_sorted_cap = 0, pts_cap = 0;
@@ -496,7 +498,7 @@ int ndt_map_destroy(ndt_map *m) {
   }
   e = hipStreamSynchronize(m->ctx->stream);
   if (m->ctx->side) e = hipStreamSynchronize(m->ctx->side);
-  void *bufs[] = {m->occ, m->tiles, m->big, m->count, m->start, m->tile, m->npts_grid, m->perm, m->perm_sorted, m->pts,
+  void *bufs[] = {m->occ, m->tiles, m->big, m->count, m->start, m->scan_state, m->npts_grid, m->perm, m->perm_sorted, m->pts,
                   m->cent, m->rec, m->bounds, m->counters, m->total, m->d_xy_stage};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
@@ -524,7 +526,10 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
     if (m->count_cap != count_cap_before) m->count_clean = false;      // a new allocation
     if ((rc = ensure_t(ctx, &m->start, &m->start_cap, ng + 1 + 8))) return rc;   // 4 readable ints before, 3 after (nearest_sq)
     if ((rc = ensure_t(ctx, &m->npts_grid, &m->npts_cap, ng + 1))) return rc;
-    if ((rc = ensure_t(ctx, &m->tile, &m->tile_cap, ntiles_ + 1))) return rc;
+    const size_t state_cap_before = m->scan_state_cap;
+    if ((rc = ensure_t(ctx, &m->scan_state, &m->scan_state_cap, 2 * ntiles_ + 2))) return rc;
+    if (m->scan_state_cap != state_cap_before)      // a new allocation: no word may carry a tag by accident
+      HIP_TRY(ctx, hipMemsetAsync(m->scan_state, 0, m->scan_state_cap * sizeof(unsigned long long), st));
     if ((rc = ensure_t(ctx, &m->perm, &m->perm_cap, n + 4))) return rc;       // + 4: map_order_kernel reads four numbers at a time
     if ((rc = ensure_t(ctx, &m->big, &m->big_cap, n / kBigVoxel + 1))) return rc;   // voxels with > kBigVoxel points
     if ((rc = ensure_t(ctx, &m->occ, &m->occ_cap, (ng + 31) / 32 + 2))) return rc;
@@ -535,7 +540,8 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   }
   // No clearing in the steady state (every memset is a kernel of its own between the build's kernels): the per-voxel
   // counters are zero again after a complete build (map_scatter_kernel takes back what map_count_kernel added), the
-  // three small counters are cleared by scan_tile_offsets_kernel, the readable ints in front of `start` by scan_apply_kernel.
+  // four small counters are cleared by map_count_kernel, the scan's words carry the build's tag, the readable ints in
+  // front of `start` are written by scan_onepass_kernel.
   if (!m->count_clean) HIP_TRY(ctx, hipMemsetAsync(m->count, 0, m->count_cap * sizeof(int), st));
   m->count_clean = false;
   // (records of voxels outside the search set are never read: no clearing of m->rec)
@@ -552,14 +558,14 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   HIP_TRY(ctx, hipEventRecord(ctx->ev_join, ctx->side));
 
   // 3. bucket the points by voxel, cloud order kept inside a bucket
-  map_count_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, m->count);
+  map_count_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, m->count, m->counters);
   const int ntiles = (int)((ng + kScanTile - 1) / kScanTile);
-  scan_tile_sums_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, m->counters);
   int *const start = m->start + 4;
   const int big_cap = (int)(n / kBigVoxel + 1);
-  const int prefixed = ntiles > kScanDirect ? 1 : 0;
-  if (prefixed) scan_tile_offsets_kernel<<<1, 1024, 0, st>>>(m->tile, ntiles);
-  scan_apply_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->tile, ntiles, prefixed, start, m->big, m->counters + 2, big_cap);
+  m->scan_seq = (m->scan_seq + 1u) & 0x3fffffffu;
+  if (m->scan_seq == 0u) m->scan_seq = 1u;
+  scan_onepass_kernel<<<ntiles, kScanBlock, 0, st>>>(m->count, ng, m->scan_state, m->scan_seq, ntiles, m->counters + 3, start,
+                                                     m->big, m->counters + 2, big_cap);
   map_scatter_kernel<<<grid_for(n, 256), 256, 0, st>>>(xy, stride, n, G, start, m->count, m->perm);
   HIP_TRY(ctx, hipGetLastError());
   m->count_clean = true;
@@ -571,9 +577,10 @@ static int queue_build(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   LeafParams L;
   L.min_pts = prm->min_pts; L.cov_unbiased = prm->cov_unbiased; L.cov_init_identity = prm->cov_init_identity;
   L.eig_mult = prm->eig_mult;
-  map_finalize_kernel<<<(unsigned)((ng + 255) / 256), 256, 0, st>>>(G, L, start,
-                                                                          m->pts, m->cent, m->rec, m->npts_grid,
-                                                                          m->counters, m->occ, m->tiles, tiles_w);
+  // evm1 -- the end of the build, for ndt_kernel timing and for launches on other streams -- rides on this kernel's own
+  // dispatch (an hipEventRecord is a packet of its own: ~6 us between two kernels, tools/launch_gap.py)
+  hipExtLaunchKernelGGL(map_finalize_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, st, nullptr, ctx->evm1, 0, G, L, start,
+                        m->pts, m->cent, m->rec, m->npts_grid, m->counters, m->occ, m->tiles, tiles_w);
   HIP_TRY(ctx, hipGetLastError());
 
   MapView &V = m->view;
@@ -599,11 +606,11 @@ static int build_begin(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   m->prm = *prm; m->n = n; m->info_valid = false;
   m->pend_xy = xy; m->pend_stride = stride; m->pend_queued = false;
   m->readers.clear();                          // whoever read the previous build is the caller's to wait for (stream order / ndt_ctx_wait_launch)
-  HIP_TRY(ctx, hipEventRecord(ctx->evm0, st));
   // The bounding box (and the reset of the centroid grid, queue_build) run on a side stream beside the bucketing
   // chain -- a dozen dependent kernels whose launch latencies add up -- and are joined in front of the statistics.
-  HIP_TRY(ctx, hipEventRecord(ctx->ev_fork, st));
-  HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  // (One record serves as the start of the build's timing and as the fork.)
+  HIP_TRY(ctx, hipEventRecord(ctx->evm0, st));
+  HIP_TRY(ctx, hipStreamWaitEvent(ctx->side, ctx->evm0, 0));
   map_minmax_kernel<<<grid_for(n, 256 * 32, 128), 256, 0, ctx->side>>>(xy, stride, n, m->bounds, m->bounds + 4);
   HIP_TRY(ctx, hipMemcpyAsync(ctx->h_bounds, m->bounds + 4, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->side));
   HIP_TRY(ctx, hipEventRecord(ctx->evb, ctx->side));
@@ -611,8 +618,7 @@ static int build_begin(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   if (m->have_grid && m->grid.inv_leaf == inv_leaf) {
     int rc = queue_build(ctx, m, xy, n, stride, prm, m->grid);
     if (rc) return rc;
-    m->pend_queued = true;
-    HIP_TRY(ctx, hipEventRecord(ctx->evm1, st));           // what launches queued before build_end wait for
+    m->pend_queued = true;                                 // (evm1, what launches queued before build_end wait for: queue_build)
   }
   m->pending = true;
   ctx->pending_map = m;
@@ -669,7 +675,6 @@ static int build_end(ndt_ctx *ctx, ndt_map *m) {
     redone = m->pend_queued ? 1 : 0;
   }
   m->grid = G; m->have_grid = true;
-  if (!same) HIP_TRY(ctx, hipEventRecord(ctx->evm1, st));
   ctx->map_ms_pending = true;
   return redone;                               // asynchronous from here on (stream order)
 }

@@ -292,8 +292,9 @@ def test_map_destroy_closes_an_open_rebuild(gpu, c1_world):
 
 
 def test_sparse_grid_above_the_direct_scan_limit(gpu, oracle):
-    """A grid of more than 4096 scan tiles (8.4M voxels): the bucket offsets come from the one-workgroup tile scan
-    (scan_tile_offsets_kernel) instead of every workgroup adding up all tile sums in front of it."""
+    """A grid of more than 8M voxels, mostly empty: over a thousand tiles of the single-pass offsets scan
+    (scan_onepass_kernel) -- several look-back windows per tile, and more tiles than workgroups are resident at once (the
+    ticket hands tiles out in the order workgroups start)."""
     capi, ctx = gpu
     rng = np.random.default_rng(11)
     a = rng.normal(0.0, 3.0, size=(6000, 2))
