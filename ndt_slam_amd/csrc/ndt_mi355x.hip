@@ -638,9 +638,10 @@ static int build_end(ndt_ctx *ctx, ndt_map *m) {
   const float mnx = ord2f(hb[0]), mny = ord2f(hb[1]), mxx = ord2f(hb[2]), mxy = ord2f(hb[3]);
   GridDims G;
   G.inv_leaf = inv_leaf;
-  G.min_bx = (int)floorf(mnx * inv_leaf); G.min_by = (int)floorf(mny * inv_leaf);
-  long long dx = (long long)(int)floorf(mxx * inv_leaf) - G.min_bx + 1;
-  long long dy = (long long)(int)floorf(mxy * inv_leaf) - G.min_by + 1;
+  auto vox = [&](float x) { return (int)fminf(fmaxf(floorf(x * inv_leaf), -1.0e9f), 1.0e9f); };   // (as voxel_of: a float beyond the int range)
+  G.min_bx = vox(mnx); G.min_by = vox(mny);
+  long long dx = (long long)vox(mxx) - G.min_bx + 1;
+  long long dy = (long long)vox(mxy) - G.min_by + 1;
   // ndt_params::grid_margin: the grid queued ahead is good if it contains the cloud's box and is not much wider
   const int mg = prm->grid_margin > 0 ? (prm->grid_margin < 4096 ? prm->grid_margin : 4096) : 0;
   bool same = false;
@@ -654,7 +655,8 @@ static int build_end(ndt_ctx *ctx, ndt_map *m) {
   if (same) G = m->grid;
   else {
     G.min_bx -= mg; G.min_by -= mg; dx += 2 * mg; dy += 2 * mg;
-    if (dx * dy > (1LL << 28)) return fail(ctx, NDT_E_GRID, "ndt_map_build: voxel grid larger than 2^28 cells");
+    if (dx > (1LL << 28) || dy > (1LL << 28) || dx * dy > (1LL << 28))      // (each factor first: the product of two 2^32s overflows)
+      return fail(ctx, NDT_E_GRID, "ndt_map_build: voxel grid larger than 2^28 cells");
     G.div_x = (int)dx; G.div_y = (int)dy; G.gw = G.div_x + 4; G.gh = G.div_y + 4;
   }
   int redone = 0;

@@ -781,6 +781,14 @@ def test_error_behaviour(gpu):
         capi.Map(ctx, np.full((10, 2), np.nan, np.float32), capi.default_params(resolution=0.5))
     with pytest.raises(capi.NdtError):     # 2^28 voxel limit
         capi.Map(ctx, np.array([[0, 0], [1e6, 1e6]], np.float32), capi.default_params(resolution=0.01))
+    for far in (3e9, 1e20, 3e38):          # voxel coordinates beyond the int range: refused as a grid too large, nothing overflows
+        with pytest.raises(capi.NdtError):
+            capi.Map(ctx, np.array([[-far, -far], [0, 0], [far, far]], np.float32), capi.default_params(resolution=0.5))
+    with pytest.raises(capi.NdtError):     # the margin counts
+        capi.Map(ctx, np.array([[0, 0], [8000.0, 8000.0]], np.float32), capi.default_params(resolution=0.5, grid_margin=200))
+    ok = capi.Map(ctx, np.array([[0, 0], [8000.0, 8000.0]], np.float32), capi.default_params(resolution=0.5))
+    assert ok.info().div_x == 16001
+    ok.close()
     gm = capi.Map(ctx, np.random.default_rng(0).uniform(0, 5, (500, 2)).astype(np.float32),
                   capi.default_params(resolution=0.5))
     with pytest.raises(capi.NdtError):
