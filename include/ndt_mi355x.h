@@ -15,7 +15,8 @@
  * synchronous on return; *_dev calls are asynchronous on their stream.  A context owns one set of
  * scratch buffers: *_dev calls of ONE context on different streams are serialised by the library (the
  * later call's stream waits for the earlier call's kernels); to have two batches in flight at the
- * same time use two contexts (a map may be read by any context of its device).
+ * same time use two contexts (a map may be read by any context of its device, from its own host thread: the
+ * map's bookkeeping of who reads it is locked; a map is REBUILT from one thread at a time, that of its context).
  */
 #ifndef NDT_MI355X_H_
 #define NDT_MI355X_H_

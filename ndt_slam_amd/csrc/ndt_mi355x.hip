@@ -290,6 +290,7 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   }
   {                                           // this launch reads the map: a re-queued build must wait for it (ndt_map::readers)
     auto &rd = const_cast<ndt_map *>(map)->readers;
+    std::lock_guard<std::mutex> lk(g_live_mu);           // (launches on several contexts may come from several host threads)
     bool found = false;
     for (auto &r : rd) if (r.first == ctx) { r.second = ctx->launches; found = true; }
     if (!found) rd.emplace_back(ctx, ctx->launches);
@@ -605,7 +606,7 @@ static int build_begin(ndt_ctx *ctx, ndt_map *m, const float *xy, size_t n, size
   hipStream_t st = ctx->stream;
   m->prm = *prm; m->n = n; m->info_valid = false;
   m->pend_xy = xy; m->pend_stride = stride; m->pend_queued = false;
-  m->readers.clear();                          // whoever read the previous build is the caller's to wait for (stream order / ndt_ctx_wait_launch)
+  { std::lock_guard<std::mutex> lk(g_live_mu); m->readers.clear(); }   // whoever read the previous build is the caller's to wait for (stream order / ndt_ctx_wait_launch)
   // The bounding box (and the reset of the centroid grid, queue_build) run on a side stream beside the bucketing
   // chain -- a dozen dependent kernels whose launch latencies add up -- and are joined in front of the statistics.
   // (One record serves as the start of the build's timing and as the fork.)
@@ -664,7 +665,9 @@ static int build_end(ndt_ctx *ctx, ndt_map *m) {
     if (m->pend_queued) {
       // the launches queued since build_begin read the speculative build's tables: the build that replaces them waits
       // for the last of them on every context that issued any (the event on that launch's last kernel)
-      for (auto &r : m->readers) {
+      std::vector<std::pair<ndt_ctx *, unsigned long long>> readers;
+      { std::lock_guard<std::mutex> lk(g_live_mu); readers = m->readers; }
+      for (auto &r : readers) {
         ndt_ctx *rc_ = r.first;
         bool alive; { std::lock_guard<std::mutex> lk(g_live_mu); alive = g_live_ctx.count(rc_) != 0; }
         if (!alive || rc_->launches <= r.second || rc_->launches - 1 - r.second >= (unsigned long long)ndt_ctx::kTimeRing) continue;
