@@ -271,11 +271,41 @@ __device__ __noinline__ bool advance_step(AlignState &S, const OptParams &P) {
   return true;
 }
 
+// The pass the reference would run next is the pass it has just run: the line search asked for the SAME step length
+// again.  More-Thuente's trial value is clamped from below to trans_eps / 2 (PCL: `a_t = std::max (a_t, step_min)`), and once
+// a search is down there every further trial is that value -- the same x_t, the same float32 matrix, the same cloud,
+// hence, operation for operation, the same score, gradient and Hessian -- until the search has used up its ten
+// iterations: on the bench workload 29 of 256 matches end in eleven such passes (the 13-20-pass matches every launch
+// waits for; `tools/...`: LOG R4.9).  The totals of the last pass ARE the totals of that pass: it is counted
+// (ref_evals), logged, and not run.
+__device__ __noinline__ void repeat_totals(AlignState &S, double *trace, int trace_cap, int *trace_rows) {
+  S.ref_evals = S.ref_evals + 1;
+  if (trace) {
+    int row = *trace_rows;
+    if (row < trace_cap) {
+      double *t = trace + 8 * (size_t)row;
+      t[0] = S.a_t; t[1] = S.score;
+      t[2] = S.g[0]; t[3] = S.g[1]; t[4] = S.g[2]; t[5] = S.xt[0]; t[6] = S.xt[1]; t[7] = S.xt[2];
+    }
+    *trace_rows = row + 1;
+  }
+}
+
 __device__ __forceinline__ void advance(AlignState &S, const OptParams &P, const MapView &M,
                                         const double tot[kAcc], double *trace, int trace_cap,
                                         int *trace_rows) {
   advance_totals(S, M, tot, trace, trace_cap, trace_rows);
-  if (advance_step(S, P)) begin_outer(S, P);
+  for (int turn = 0; turn < 64; ++turn) {            // (a line search has mt_max_iter turns at most)
+    const double a_prev = S.a_t;
+    const int ph_prev = S.phase;
+    if (advance_step(S, P)) { begin_outer(S, P); return; }
+#ifdef NDT_NO_REPEAT_SKIP
+    return;
+#endif
+    // a new trial inside the same line search (same p, same direction) with the step length of the pass just consumed?
+    if (S.phase != PH_LS_INNER || ph_prev == PH_INIT || !(S.a_t == a_prev)) return;
+    repeat_totals(S, trace, trace_cap, trace_rows);
+  }
 }
 
 __device__ __noinline__ void init_state(AlignState &S, const OptParams &P, const double init[3],

@@ -36,8 +36,10 @@ def assert_result_parity(r, ref, exact_path=True):
         assert (r["T00"], r["T10"], r["T03"], r["T13"]) == (ref["T00"], ref["T10"], ref["T03"], ref["T13"])
         assert r["fitness"] == pytest.approx(ref["fitness"], rel=1e-12)
         assert r["score"] == pytest.approx(ref["score"], rel=1e-9)
-        # the oracle also averages over its Hessian-only passes, which are fused away here
-        assert r["kbar"] == pytest.approx(ref["kbar"], rel=0.2)
+        # kbar is roofline accounting over the passes each side RUNS: the oracle also runs the Hessian-only passes (fused away
+        # here) and, like the reference, every pass of a line search that asks for the same step length again (not run
+        # here: same pose, same totals); the pair counts themselves are held exactly by the single-evaluation tests
+        assert r["kbar"] == pytest.approx(ref["kbar"], rel=0.35)
         assert int(r["evals"]) <= int(r["ref_evals"]) - 1
         Hs = np.abs(ref["H"]).max()
         assert r["H"] == pytest.approx(ref["H"], rel=1e-8, abs=1e-9 * Hs)
