@@ -40,6 +40,7 @@ constexpr int kMaxHelpers = NDT_MAX_HELPERS_BUILD;   // helper workgroups per sc
 // and a workgroup that finds every unfinished scan at its limit leaves -- its CU goes to whatever is queued behind
 // the launch (in the bench: the map build of the next step).  8 against 15: same kernel time, 1.6 % more matches/s.
 constexpr int kDefaultHelpers = 8;
+constexpr int kBatchHelpers = 4;           // launches with a scan for every workgroup (ndt_mi355x.hip: launch_align)
 #ifndef NDT_IDLE_MAX
 #define NDT_IDLE_MAX 800           // idle helper back-off: 4 us doubling up to 8 us (100 MHz ticks)
 #endif

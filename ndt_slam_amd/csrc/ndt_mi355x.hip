@@ -87,7 +87,7 @@ struct ndt_ctx {
   void *h_mm = nullptr; size_t h_mm_cap = 0;           // pinned staging of the job table
   hipEvent_t ev_mm = nullptr; bool mm_pending = false; // job table upload of the previous call
   int num_cus = 0;
-  int helpers = 1;                                     // NDT_OPT_MAX_HELPERS: helper workgroups per scan (0: no work sharing)
+  int helpers = -1;                                    // NDT_OPT_MAX_HELPERS: helper workgroups per scan (0: no work sharing; -1: by the size of the launch)
   int workgroups = 0;                                  // NDT_OPT_WORKGROUPS: workgroups of a match launch (0: one per CU)
   // The grow-only scratch above belongs to the context, not to a stream: a call on another stream than the
   // previous one first waits for the previous user (ev_scratch).
@@ -250,7 +250,10 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   if (ctx->ws_clean < zero_bytes) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ws, 0, zero_bytes, st));
   ctx->ws_clean = 0;
   unsigned char *ws = (unsigned char *)ctx->d_ws;
-  const int helpers = ctx->helpers;
+  // helper limit: 8 while a launch has fewer scans than workgroups (one scan at a time: everybody helps), 4 for whole-GPU
+  // batches -- there the match kernel is as fast with 2 as with 15, and workgroups that find nothing to join leave their
+  // CUs to the next step's map build earlier (round 4, after the repeated line-search passes went: LOG R4.9)
+  const int helpers = ctx->helpers >= 0 ? ctx->helpers : (B >= (ctx->workgroups > 0 ? ctx->workgroups : ctx->num_cus) ? kBatchHelpers : kDefaultHelpers);
   // one workgroup per CU (the LDS window allows no more); idle workgroups help unfinished scans
   const int ncu = ctx->workgroups > 0 ? ctx->workgroups : ctx->num_cus;
   const int grid = helpers ? ncu : (B < ncu ? B : ncu);
@@ -372,7 +375,7 @@ static int ctx_init(ndt_ctx *c, int device) {
   hipDeviceProp_t prop;
   HIP_TRY(c, hipGetDeviceProperties(&prop, device));
   c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
-  c->helpers = kDefaultHelpers;
+  c->helpers = -1;                          // automatic (launch_align)
   return NDT_OK;
 }
 
@@ -396,7 +399,7 @@ int ndt_ctx_set_option(ndt_ctx *c, int option, long long value) {
   if (!c) return NDT_E_ARG;
   switch (option) {
     case NDT_OPT_MAX_HELPERS:
-      if (value < 0 || value > kMaxHelpers) return fail(c, NDT_E_ARG, "NDT_OPT_MAX_HELPERS: 0 .. 15");
+      if (value < -1 || value > kMaxHelpers) return fail(c, NDT_E_ARG, "NDT_OPT_MAX_HELPERS: 0 .. 15, or -1 for the default");
       c->helpers = (int)value; return NDT_OK;
     case NDT_OPT_WORKGROUPS:
       if (value < 0 || value > c->num_cus) return fail(c, NDT_E_ARG, "NDT_OPT_WORKGROUPS: 0 (one per CU) .. number of CUs");

@@ -276,7 +276,7 @@ __device__ __noinline__ bool advance_step(AlignState &S, const OptParams &P) {
 // a search is down there every further trial is that value -- the same x_t, the same float32 matrix, the same cloud,
 // hence, operation for operation, the same score, gradient and Hessian -- until the search has used up its ten
 // iterations: on the bench workload 29 of 256 matches end in eleven such passes (the 13-20-pass matches every launch
-// waits for; `tools/...`: LOG R4.9).  The totals of the last pass ARE the totals of that pass: it is counted
+// waits for; tools/pass_counts.py, LOG R4.9).  The totals of the last pass ARE the totals of that pass: it is counted
 // (ref_evals), logged, and not run.
 __device__ __noinline__ void repeat_totals(AlignState &S, double *trace, int trace_cap, int *trace_rows) {
   S.ref_evals = S.ref_evals + 1;
