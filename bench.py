@@ -524,9 +524,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "note": "achieved = SURVEY 8d algorithmic bytes of the match kernel's passes (E x N x (8 + 20 Kbar) per "
-                                 "match) / duration of one launch of that kernel.  The kernel is VALU-issue bound, not HBM bound: "
+                                 "match, E = the derivative passes actually RUN: a line-search trial that repeats the step length "
+                                 "of the pass before it -- a sixth of the reference's passes on this workload -- has that pass's "
+                                 "totals and is not run again, DESIGN.md 4.2; `ref_evals_mean` counts what the reference runs) / "
+                                 "duration of one launch of that kernel.  The kernel is VALU-issue bound, not HBM bound: "
                                  "each voxel record is staged once per match in LDS, so the measured HBM traffic is below the "
-                                 "algorithmic bytes (DESIGN.md 4.7).  The fitness score (N x 16 B per match) is a kernel of its "
+                                 "algorithmic bytes (DESIGN.md 4.2).  The fitness score (N x 16 B per match) is a kernel of its "
                                  "own, listed under `fitness`",
                          "kernel": "ndt_align_kernel", "kernel_ms": avg_kern_ms,
                          "launch_interval_ms": float(np.mean(kern_ms)) if kern_ms else None,
@@ -538,6 +541,7 @@ def main():
                          "map_build": map_build_roofline,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "mean_evals": float(res["evals"].mean()), "max_evals": int(res["evals"].max()),
+                         "ref_evals_mean": float(res["ref_evals"].mean()),
                          "mean_kbar": float(res["kbar"].mean())},
             "map_build_ms": float(np.median(solo_build_ms)), "map_build_in_step_ms": float(np.mean(map_ms)) if map_ms else None,
             "converged": int(res["converged"].sum()),
@@ -818,7 +822,8 @@ def main():
         out["cpu_baseline"] = {
             "value": ns / t_align, "unit": "matches/s", "cores": 1, "kind": "port",
             "sample": "first %d of the %d matches, median of %d repetitions (one warm-up excluded), 1 thread, map built once "
-                      "(amortised); oracle/ndt_oracle.c, -O2, grid-hash neighbour lookup (faster than PCL's kd-tree)" % (ns, B, reps),
+                      "(amortised); oracle/ndt_oracle.c, -O2, grid-hash neighbour lookup (faster than PCL's kd-tree); it runs every "
+                      "derivative pass the reference runs, the repeated line-search trials included" % (ns, B, reps),
             "cpu_model": cpu_model(), "nproc": os.cpu_count(),
             "map_build_s": t_build,
             "reference_faithful_matches_per_s": 1.0 / (t_build + t_align / ns),
