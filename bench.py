@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="matches per GPU and step (default 256 for C3, 512 for C5)")
     ap.add_argument("--inflight", type=int, default=1, choices=[1, 2, 3, 4], help="match launches in flight (k: k contexts / streams in turn, k + 1 map buffers)")
     ap.add_argument("--workgroups", type=int, default=0, help="workgroups per match launch (0 = one per CU); fewer leave CUs to the map build's stream")
-    ap.add_argument("--max-helpers", type=int, default=-1, help="helper workgroups per unfinished scan (default -1: the library chooses, 4 for whole-GPU batches and 8 below); fewer free CUs earlier for whatever is queued behind the launch")
+    ap.add_argument("--max-helpers", type=int, default=-1, help="helper workgroups per unfinished scan (default -1: the library chooses, 2 for whole-GPU batches and 8 below); fewer free CUs earlier for whatever is queued behind the launch")
     ap.add_argument("--time-builds", action="store_true", help="extra events around the map build and around the whole launch inside the step loop (launch_interval_ms, map_build_in_step_ms)")
     ap.add_argument("--no-scatter", action="store_true", help="N > 1: every rank generates its own shard instead of receiving it from rank 0")
     ap.add_argument("--map-from-rank0", action="store_true", help="N > 1: only rank 0 generates the target cloud, the others build their map from shard.broadcast_map's copy (by default every rank generates it AND the broadcast is timed and checked against it: comm.broadcast_map_ms)")

@@ -143,7 +143,7 @@ const char *ndt_last_error(const ndt_ctx *ctx);   /* ctx may be NULL: last globa
 void *ndt_ctx_stream(ndt_ctx *ctx);               /* hipStream_t the context works on   */
 /* Tuning of the match launch (defaults are right for whole-GPU batches):
  *   NDT_OPT_MAX_HELPERS  0..15  workgroups that may join the passes of one unfinished scan; 0 = no work sharing;
- *                               -1 = the default: 8, or 4 when the launch has a scan for every workgroup
+ *                               -1 = the default: 8, or 2 when the launch has a scan for every workgroup
  *   NDT_OPT_WORKGROUPS   0..#CU workgroups per match launch (0 = one per CU); a smaller value leaves CUs to
  *                               other streams
  * Results never depend on either (unit totals are summed in unit order whoever computed them). */

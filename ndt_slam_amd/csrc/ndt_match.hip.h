@@ -40,12 +40,15 @@ constexpr int kMaxHelpers = NDT_MAX_HELPERS_BUILD;   // helper workgroups per sc
 // and a workgroup that finds every unfinished scan at its limit leaves -- its CU goes to whatever is queued behind
 // the launch (in the bench: the map build of the next step).  8 against 15: same kernel time, 1.6 % more matches/s.
 constexpr int kDefaultHelpers = 8;
-constexpr int kBatchHelpers = 4;           // launches with a scan for every workgroup (ndt_mi355x.hip: launch_align)
+constexpr int kBatchHelpers = 2;           // launches with a scan for every workgroup (ndt_mi355x.hip: launch_align)
 #ifndef NDT_IDLE_MAX
 #define NDT_IDLE_MAX 800           // idle helper back-off: 4 us doubling up to 8 us (100 MHz ticks)
 #endif
 #ifndef NDT_XCD_BONUS
 #define NDT_XCD_BONUS 6          // passes' worth of preference for scans owned on the helper's own XCD (0: off)
+#endif
+#ifndef NDT_NEED_SLOPE
+#define NDT_NEED_SLOPE 10       // passes still to run per unit of (1 - score per point / best score per point of a finished scan)
 #endif
 #ifndef NDT_HELPER_PENALTY
 #define NDT_HELPER_PENALTY 12    // passes a scan must be ahead by before it gets one more helper than another
@@ -120,11 +123,12 @@ struct alignas(128) ScanCtl {
   u32 use_sorted;    //         1: passes read the scan from the sorted scratch copy
   u32 claimed;       //         1: a workgroup owns this scan (compare-and-swap; see "claims" in the kernel)
   u32 owner_xcd;     //         1 + XCD of the owning workgroup (helpers of the same XCD share its L2)
-  int pad2_[20];
+  u32 spp;           //         float bits: score per point after the last pass (what is left to do shows in it: see the helper's choice)
+  int pad2_[19];
 };
 static_assert(sizeof(ScanCtl) == 256, "ScanCtl is two 128-byte lines");
 
-struct WsHeader { u32 done; u32 abort; u32 next; u32 pad[29]; };   // next: scans handed out beyond the first gridDim.x
+struct WsHeader { u32 done; u32 abort; u32 next; u32 best_spp; u32 pad[28]; };   // next: scans handed out beyond the first gridDim.x; best_spp: float bits, best score per point of a finished scan
 static_assert(sizeof(WsHeader) == 128, "WsHeader");
 
 #define NDT_RLX __ATOMIC_RELAXED
@@ -1127,7 +1131,11 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         const int h = allow_helpers ? min(L.sflag[1], kMaxHelpers) : 0;
         L.sflag[0] = h;
         L.jnext = 0;
-        if (allow_helpers) st32(&C->passes, (u32)L.S.evals);
+        if (allow_helpers) {
+          st32(&C->passes, (u32)L.S.evals);
+          const float spp = (float)(L.S.score / (double)n);
+          st32(&C->spp, spp > 0.f ? __float_as_uint(spp) : 0u);
+        }
         if (h > 0) {                            // open an epoch: the pose halves and the epoch word, all under its tag
           const u64 tg = (u64)(epoch + 1) << 32;
           const u64 dj = (u64)__double_as_longlong(pp.cj), ds = (u64)__double_as_longlong(pp.sj);
@@ -1270,6 +1278,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       results[b] = R_;
       if (allow_helpers) {
         st64(&C->ticket, (u64)kEpochDone << 32);
+        const float spp = n > 0 ? (float)(S.score / (double)n) : 0.f;
+        if (S.converged && spp > 0.f) __hip_atomic_fetch_max(&hdr->best_spp, __float_as_uint(spp), NDT_RLX, NDT_AGENT);   // (positive floats order like their bits)
         __hip_atomic_fetch_add(&hdr->done, 1u, NDT_RLX, NDT_AGENT);
       }
       if (kProf && prof) {
@@ -1322,6 +1332,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     // up to kMaxHelpers, a unit each per wave)
     const int unfinished = max(1, B - (int)ld32(&hdr->done));
     const int room = min(allow_helpers, max(min(allow_helpers, kBaseHelpers), (int)gridDim.x / unfinished - 1));
+    const float best_spp = __uint_as_float(ld32(&hdr->best_spp));
     for (int k = threadIdx.x; k < B; k += kBlock) {
       int b = start + k; if (b >= B) b -= B;
       const u32 ep = (u32)(rd64_fresh(&ctl[b].ticket) >> 32);
@@ -1329,11 +1340,21 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       if (ep == kEpochDone) continue;
       const u32 h = rd32_fresh(&ctl[b].helpers);
       if (h >= (u32)room) continue;
-      // a scan that already needed many passes will likely need many more: most passes first,
-      // each attached helper counting like 4 passes fewer; then nearest
-      const int score = (int)min(ld32(&ctl[b].passes), 200u) - NDT_HELPER_PENALTY * (int)h +
-                        ((NDT_XCD_BONUS && ld32(&ctl[b].owner_xcd) == 1u + (blockIdx.x & 7u)) ? NDT_XCD_BONUS : 0);
-      atomicMin(&L.sflag[0], (int)(((u32)(512 - score) << 20) | (u32)k));
+      // Which scan has most left to do?  Its score per point says: against the best a FINISHED scan of this launch reached,
+      // 1.00 / 0.97 / 0.8 / 0.7 / 0.5 / 0.4 of it go with 1 / 2 / 3 / 4 / 5 / 6-7 passes still to run (bench workload,
+      // tools/pass_counts.py: the score alone explains 65-78 % of the variance of what is left; the passes run so far --
+      // the rule until round 4 -- nothing once the repeated passes were gone).  In quarter passes; every attached helper
+      // counts like NDT_HELPER_PENALTY passes fewer, an owner on this XCD like NDT_XCD_BONUS more; then nearest.
+      int need4;
+#ifndef NDT_NO_NEED_POLICY
+      const float spp = __uint_as_float(ld32(&ctl[b].spp));
+      if (best_spp > 0.f) need4 = (int)(4.f * fminf(fmaxf(1.f + (float)NDT_NEED_SLOPE * (1.f - spp / best_spp), 0.f), 12.f));
+      else
+#endif
+        need4 = 4 * (int)min(ld32(&ctl[b].passes), 12u);
+      const int score = need4 - 4 * NDT_HELPER_PENALTY * (int)h +
+                        ((NDT_XCD_BONUS && ld32(&ctl[b].owner_xcd) == 1u + (blockIdx.x & 7u)) ? 4 * NDT_XCD_BONUS : 0);
+      atomicMin(&L.sflag[0], (int)(((u32)(1024 - score) << 20) | (u32)k));
     }
     __syncthreads();
     if (threadIdx.x == 0) {

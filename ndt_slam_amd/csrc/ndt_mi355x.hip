@@ -250,7 +250,7 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   if (ctx->ws_clean < zero_bytes) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ws, 0, zero_bytes, st));
   ctx->ws_clean = 0;
   unsigned char *ws = (unsigned char *)ctx->d_ws;
-  // helper limit: 8 while a launch has fewer scans than workgroups (one scan at a time: everybody helps), 4 for whole-GPU
+  // helper limit: 8 while a launch has fewer scans than workgroups (one scan at a time: everybody helps), 2 for whole-GPU
   // batches -- there the match kernel is as fast with 2 as with 15, and workgroups that find nothing to join leave their
   // CUs to the next step's map build earlier (round 4, after the repeated line-search passes went: LOG R4.9)
   const int helpers = ctx->helpers >= 0 ? ctx->helpers : (B >= (ctx->workgroups > 0 ? ctx->workgroups : ctx->num_cus) ? kBatchHelpers : kDefaultHelpers);
