@@ -94,8 +94,9 @@ typedef struct ndt_result {
   double p[3];        /* final fp64 parameter vector (tx, ty, yaw)                                 */
   int    iters;       /* outer Newton iterations                                                   */
   int    evals;       /* derivative passes this library executed                                   */
-  int    ref_evals;   /* passes the reference executes on the same path (adds its Hessian-only
-                         passes and the getHessian pass, which are fused here)                     */
+  int    ref_evals;   /* passes the reference executes on the same path: adds its Hessian-only passes and the
+                         getHessian pass (fused here) and the trials of a line search that repeat the step length
+                         of the pass before them (same pose, same totals: not run again here)      */
   int    converged;   /* hasConverged() (src/PoseEstimator.cpp:44)                                 */
   int    status;      /* ndt_status of this match                                                  */
   int    flags;       /* NDT_FLAG_* bits: which data path the match took (results do not depend on it)    */
