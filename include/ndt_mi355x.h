@@ -147,8 +147,12 @@ void *ndt_ctx_stream(ndt_ctx *ctx);               /* hipStream_t the context wor
  *                               -1 = the default: 8, or 2 when the launch has a scan for every workgroup
  *   NDT_OPT_WORKGROUPS   0..#CU workgroups per match launch (0 = one per CU); a smaller value leaves CUs to
  *                               other streams
- * Results never depend on either (unit totals are summed in unit order whoever computed them). */
-enum ndt_option { NDT_OPT_MAX_HELPERS = 1, NDT_OPT_WORKGROUPS = 2 };
+ * Results never depend on either (unit totals are summed in unit order whoever computed them).
+ *   NDT_OPT_INJECT_FAULT k      test instrumentation for the error paths: the k-th next match launch of the context returns
+ *                               NDT_E_HIP right behind the dispatch of its first kernel (0 = off, the default).  The call
+ *                               leaves the context usable: the kernel that was queued is ordered in front of whatever any
+ *                               stream does with the context next. */
+enum ndt_option { NDT_OPT_MAX_HELPERS = 1, NDT_OPT_WORKGROUPS = 2, NDT_OPT_INJECT_FAULT = 3 };
 int ndt_ctx_set_option(ndt_ctx *ctx, int option, long long value);
 /* Make the context work on a caller-owned hipStream_t (e.g. the stream a host framework already
  * orders its copies on); NULL restores the context's own stream. */

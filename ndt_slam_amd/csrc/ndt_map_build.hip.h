@@ -230,7 +230,7 @@ map_scatter_kernel(const float *__restrict__ xy, size_t stride, size_t n, GridDi
 // 8-byte reads -- happens here, spread over every lane of the chip, and map_finalize_kernel streams a voxel's points from
 // consecutive addresses instead of chasing number -> point through two dependent loads per batch (47 -> .. us).  Voxels of up to kBigVoxel
 // points: eight lanes per voxel (one wave per voxel spent its time launching waves, 70 % of the
-// voxels being empty); the others, listed by scan_apply_kernel: one wave per voxel.
+// voxels being empty); the others, listed by scan_onepass_kernel (the list is in voxel order): one wave per voxel.
 constexpr int kOrderVoxPerBlock = 256 / 8 * 4;     // 32 lane groups, 4 voxels each
 __device__ __forceinline__ void order_small_voxels(unsigned block, const int *__restrict__ start, size_t ng,
                                                    const int *__restrict__ perm, const float *__restrict__ xy, size_t stride,

@@ -102,6 +102,9 @@ double PoseEstimator::estimatePose(Pose2D &initPose, Pose2D &estPose, Matrix3d &
   // :43-46 fitness score, sentinel when not converged
   double cost = last_.fitness;
   if (!last_.converged) cost = kFailed;
+  // (the theta the reference hands to getHessian at :53-56 does not enter the Hessian: PCL's computeHessian ignores its `p`
+  //  argument and re-uses the angle terms of the LAST derivative pass -- those of the fp64 parameter vector, SURVEY 8a row a8 --
+  //  so neither yaw enters last_.H: the covariance belongs to the final transformation, whichever asin / acos reports its angle)
   // :53-64 covariance = (-H)^-1 * coeNDTCov (fixed-size 3x3 inverse by cofactors, as Eigen does)
   double h[9];
   for (int i = 0; i < 9; ++i) h[i] = -last_.H[i];

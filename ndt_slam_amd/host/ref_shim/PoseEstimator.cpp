@@ -69,7 +69,9 @@ double PoseEstimator::estimatePose(Pose2D &initPose, Pose2D &estPose, Eigen::Mat
   double cost = r.fitness;
   if (!r.converged) cost = kFailed;
 
-  // :53-64
+  // :53-64  (the theta handed to getHessian there does not enter the Hessian: PCL's computeHessian ignores its `p` argument and
+  // re-uses the angle terms of the last derivative pass, SURVEY 8a row a8 -- r.H belongs to the final transformation whichever
+  // asin / acos reports its angle)
   Eigen::Matrix3d hessian3d;
   hessian3d << r.H[0], r.H[1], r.H[2], r.H[3], r.H[4], r.H[5], r.H[6], r.H[7], r.H[8];
   hessian3d = -hessian3d;

@@ -566,8 +566,16 @@ typedef struct {
   angle_terms at;         /* j_ang (cj,sj) and h_ang (ch,sh) member state */
   int evals, ref_evals;
   double pairs;
+  int evals_run;          /* derivative passes the DEVICE path runs: passes with a gradient, minus the trials that repeat the */
+  double pairs_run;       /*   step length of the pass before them (ndt_optimizer.hip.h: advance); their (point, voxel) pairs   */
   double *trace; int trace_cap, trace_n;
 } align_ctx;
+
+/* ndt_oracle_set_memoise(1): a line-search trial at the step length of the pass just run re-uses that pass's totals, as the
+ * device path does (same x_t, same float32 matrix, same cloud: operation for operation the same pass).  Default 0: every pass
+ * the reference runs is run.  Either way evals_run / pairs_run count the passes the device runs.  Not thread safe to flip. */
+static int g_memoise = 0;
+void ndt_oracle_set_memoise(int on) { g_memoise = on ? 1 : 0; }
 
 static void trace_push(align_ctx *cx, double a_t, double score, const double g[3], const double p[3]) {
   if (!cx->trace || cx->trace_n >= cx->trace_cap) { cx->trace_n++; return; }
@@ -581,6 +589,13 @@ static double derivatives(align_ctx *cx, const double p[3], int with_hessian, do
   if (with_hessian || !cx->m->prm.stale_h_ang) { cx->at.ch = cx->at.cj; cx->at.sh = cx->at.sj; }
   cx->evals++; cx->ref_evals++;
   return eval_pass(cx->m, cx->scan, cx->n, cx->stride, cx->trans, cx->at, with_hessian ? 1 : 0, g, H, &cx->pairs);
+}
+/* the same, counted as a pass the device path runs too */
+static double derivatives_run(align_ctx *cx, const double p[3], int with_hessian, double g[3], double H[6]) {
+  const double before = cx->pairs;
+  const double s = derivatives(cx, p, with_hessian, g, H);
+  cx->evals_run++; cx->pairs_run += cx->pairs - before;
+  return s;
 }
 
 /* computeStepLengthMT */
@@ -607,7 +622,7 @@ static double step_length_mt(align_ctx *cx, const double x[3], double dir[3], do
   double x_t[3] = {x[0] + dir[0] * a_t, x[1] + dir[1] * a_t, x[2] + dir[2] * a_t};
   cx->T = tf_from_p(prm, x_t);
   transform_scan(prm, cx->scan, cx->n, cx->stride, cx->T, cx->trans);
-  *score = derivatives(cx, x_t, 1, g, H);
+  *score = derivatives_run(cx, x_t, 1, g, H);
   trace_push(cx, a_t, *score, g, x_t);
   double phi_t = -(*score);
   double d_phi_t = -(g[0] * dir[0] + g[1] * dir[1] + g[2] * dir[2]);
@@ -615,14 +630,26 @@ static double step_length_mt(align_ctx *cx, const double x[3], double dir[3], do
   double d_psi_t = d_phi_t - mu * d_phi_0;
   while (!interval_converged && step_iterations < prm->mt_max_iter &&
          !(psi_t <= 0 && d_phi_t <= -nu * d_phi_0)) {
+    const double a_prev = a_t;                             /* step length of the pass just run */
     if (open_interval) a_t = ndt_oracle_mt_trial(a_l, f_l, g_l, a_u, f_u, g_u, a_t, psi_t, d_psi_t);
     else               a_t = ndt_oracle_mt_trial(a_l, f_l, g_l, a_u, f_u, g_u, a_t, phi_t, d_phi_t);
     a_t = (step_max < a_t) ? step_max : a_t;
     a_t = (a_t < step_min) ? step_min : a_t;
     x_t[0] = x[0] + dir[0] * a_t; x_t[1] = x[1] + dir[1] * a_t; x_t[2] = x[2] + dir[2] * a_t;
-    cx->T = tf_from_p(prm, x_t);
-    transform_scan(prm, cx->scan, cx->n, cx->stride, cx->T, cx->trans);
-    *score = derivatives(cx, x_t, 0, g, H);
+    if (a_t == a_prev) {
+      /* the trial of the pass just run, again (the clamp at step_min does this up to mt_max_iter times): the reference
+       * transforms the cloud with the same matrix and computes the same derivatives */
+      if (g_memoise) cx->ref_evals++;                       /* counted, not run: score and g are that pass's */
+      else {
+        cx->T = tf_from_p(prm, x_t);
+        transform_scan(prm, cx->scan, cx->n, cx->stride, cx->T, cx->trans);
+        *score = derivatives(cx, x_t, 0, g, H);
+      }
+    } else {
+      cx->T = tf_from_p(prm, x_t);
+      transform_scan(prm, cx->scan, cx->n, cx->stride, cx->T, cx->trans);
+      *score = derivatives_run(cx, x_t, 0, g, H);
+    }
     trace_push(cx, a_t, *score, g, x_t);
     phi_t = -(*score);
     d_phi_t = -(g[0] * dir[0] + g[1] * dir[1] + g[2] * dir[2]);
@@ -806,9 +833,11 @@ static void init_guess(const ndt_oracle_params *prm, const double init[3], tf32 
 }
 
 /* src/PoseEstimator.cpp:17-64 with the source cloud already filtered (a1 upstream). */
-int ndt_oracle_align(const ndt_oracle_map *m, const float *scan, size_t n, size_t stride,
-                     const double init[3], ndt_oracle_result *res, double *trace, int trace_cap) {
+static int align_impl(const ndt_oracle_map *m, const float *scan, size_t n, size_t stride,
+                      const double init[3], ndt_oracle_result *res, double *trace, int trace_cap,
+                      ndt_oracle_run_stats *st) {
   memset(res, 0, sizeof(*res));
+  if (st) memset(st, 0, sizeof(*st));
   if (!m || !scan || n == 0) { res->status = -1; res->fitness = DBL_MAX; return -1; }
   const ndt_oracle_params *prm = &m->prm;
   align_ctx cx; memset(&cx, 0, sizeof(cx));
@@ -822,7 +851,7 @@ int ndt_oracle_align(const ndt_oracle_map *m, const float *scan, size_t n, size_
   transform_scan(prm, scan, n, stride, cx.T, cx.trans);   /* transformPointCloud(output, output, guess) */
 
   double g[3], H[6], score;
-  score = derivatives(&cx, p, 1, g, H);
+  score = derivatives_run(&cx, p, 1, g, H);
   trace_push(&cx, 0.0, score, g, p);
 
   int converged = 0, iters = 0, nan_exit = 0;
@@ -864,20 +893,37 @@ int ndt_oracle_align(const ndt_oracle_map *m, const float *scan, size_t n, size_
   res->flags = cx.trace_n;   /* number of trace rows (derivative passes with a gradient) */
   res->kbar = cx.pairs / ((double)cx.evals * (double)n);
   res->status = 0;
+  if (st) {
+    st->evals_run = cx.evals_run; st->pairs_run = cx.pairs_run;
+    st->kbar_run = cx.evals_run > 0 ? cx.pairs_run / ((double)cx.evals_run * (double)n) : 0.0;   /* = the device's ndt_result.kbar */
+  }
   free(cx.trans);
   return 0;
 }
 
+int ndt_oracle_align(const ndt_oracle_map *m, const float *scan, size_t n, size_t stride,
+                     const double init[3], ndt_oracle_result *res, double *trace, int trace_cap) {
+  return align_impl(m, scan, n, stride, init, res, trace, trace_cap, NULL);
+}
+int ndt_oracle_align_ex(const ndt_oracle_map *m, const float *scan, size_t n, size_t stride, const double init[3],
+                        ndt_oracle_result *res, double *trace, int trace_cap, ndt_oracle_run_stats *st) {
+  return align_impl(m, scan, n, stride, init, res, trace, trace_cap, st);
+}
+
 int ndt_oracle_align_batch(const ndt_oracle_map *m, const float *scans, const uint64_t *off, int B,
                            const double *inits, ndt_oracle_result *res, int nthreads) {
+  return ndt_oracle_align_batch_ex(m, scans, off, B, inits, res, nthreads, NULL);
+}
+int ndt_oracle_align_batch_ex(const ndt_oracle_map *m, const float *scans, const uint64_t *off, int B,
+                              const double *inits, ndt_oracle_result *res, int nthreads, ndt_oracle_run_stats *st) {
   int rc = 0;
 #ifdef _OPENMP
   if (nthreads > 1) omp_set_num_threads(nthreads);
 #pragma omp parallel for schedule(dynamic, 1) if (nthreads > 1)
 #endif
   for (int b = 0; b < B; ++b) {
-    int r = ndt_oracle_align(m, scans + 2 * off[b], (size_t)(off[b + 1] - off[b]), 2 * sizeof(float),
-                             inits + 3 * b, &res[b], NULL, 0);
+    int r = align_impl(m, scans + 2 * off[b], (size_t)(off[b + 1] - off[b]), 2 * sizeof(float),
+                       inits + 3 * b, &res[b], NULL, 0, st ? st + b : NULL);
     if (r) rc = r;
   }
   (void)nthreads;
@@ -887,13 +933,17 @@ int ndt_oracle_align_batch(const ndt_oracle_map *m, const float *scans, const ui
 /* BASELINE.json configs[4]: B initial guesses for ONE scan (multi-hypothesis relocalisation). */
 int ndt_oracle_align_seeds(const ndt_oracle_map *m, const float *scan, size_t n, int B,
                            const double *inits, ndt_oracle_result *res, int nthreads) {
+  return ndt_oracle_align_seeds_ex(m, scan, n, B, inits, res, nthreads, NULL);
+}
+int ndt_oracle_align_seeds_ex(const ndt_oracle_map *m, const float *scan, size_t n, int B,
+                              const double *inits, ndt_oracle_result *res, int nthreads, ndt_oracle_run_stats *st) {
   int rc = 0;
 #ifdef _OPENMP
   if (nthreads > 1) omp_set_num_threads(nthreads);
 #pragma omp parallel for schedule(dynamic, 1) if (nthreads > 1)
 #endif
   for (int b = 0; b < B; ++b) {
-    int r = ndt_oracle_align(m, scan, n, 2 * sizeof(float), inits + 3 * b, &res[b], NULL, 0);
+    int r = align_impl(m, scan, n, 2 * sizeof(float), inits + 3 * b, &res[b], NULL, 0, st ? st + b : NULL);
     if (r) rc = r;
   }
   (void)nthreads;

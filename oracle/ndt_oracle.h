@@ -122,6 +122,19 @@ double ndt_oracle_eval_at(const ndt_oracle_map *m, const float *scan_xy, size_t 
 int ndt_oracle_align(const ndt_oracle_map *m, const float *scan_xy, size_t n, size_t stride_bytes,
                      const double init[3], ndt_oracle_result *res, double *trace, int trace_cap);
 
+/* What the DEVICE path runs of a match, counted on the CPU side (the cheapest whole-path integer check at config scale):
+ * the derivative passes with a gradient minus the line-search trials that repeat the step length of the pass before them
+ * (the device re-uses that pass's totals, ndt_slam_amd/csrc/ndt_optimizer.hip.h: advance; Hessian-only passes and getHessian
+ * are fused away there), and the (point, voxel) pairs of exactly those passes.  kbar_run = pairs_run / (evals_run * n) is
+ * the device's ndt_result.kbar, operation for operation. */
+typedef struct ndt_oracle_run_stats { int evals_run; int pad_; double pairs_run; double kbar_run; } ndt_oracle_run_stats;
+int ndt_oracle_align_ex(const ndt_oracle_map *m, const float *scan_xy, size_t n, size_t stride_bytes, const double init[3],
+                        ndt_oracle_result *res, double *trace, int trace_cap, ndt_oracle_run_stats *st);
+/* 1: a line-search trial at the step length of the pass just run re-uses that pass's totals instead of running it again
+ * (bench.py's cpu_baseline.memoised: like for like with the passes the device runs).  Default 0 = what the reference runs.
+ * Results (transforms, iterations, ref_evals, traces) are the same either way.  Process-wide; do not flip while matches run. */
+void ndt_oracle_set_memoise(int on);
+
 /* Batch of independent matches; offsets[B+1] in points; inits B x 3.
  * nthreads <= 1: scalar loop; > 1: OpenMP over scans when built with -fopenmp. */
 int ndt_oracle_align_batch(const ndt_oracle_map *m, const float *scans_xy,
@@ -130,6 +143,11 @@ int ndt_oracle_align_batch(const ndt_oracle_map *m, const float *scans_xy,
 /* the same scan from B initial guesses (BASELINE.json configs[4]) */
 int ndt_oracle_align_seeds(const ndt_oracle_map *m, const float *scan_xy, size_t n, int B,
                            const double *inits, ndt_oracle_result *res, int nthreads);
+/* both with the run statistics of every match (st: B entries, or NULL) */
+int ndt_oracle_align_batch_ex(const ndt_oracle_map *m, const float *scans_xy, const uint64_t *offsets, int B,
+                              const double *inits, ndt_oracle_result *res, int nthreads, ndt_oracle_run_stats *st);
+int ndt_oracle_align_seeds_ex(const ndt_oracle_map *m, const float *scan_xy, size_t n, int B,
+                              const double *inits, ndt_oracle_result *res, int nthreads, ndt_oracle_run_stats *st);
 
 /* a7 alone at an explicit float32 matrix (c, s, tx, ty). */
 double ndt_oracle_fitness(const ndt_oracle_map *m, const float *scan_xy, size_t n,

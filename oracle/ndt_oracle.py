@@ -48,6 +48,25 @@ RESULT_DTYPE = np.dtype([
 assert RESULT_DTYPE.itemsize == C.sizeof(Result)
 
 
+class RunStats(C.Structure):
+    _fields_ = [("evals_run", C.c_int), ("pad_", C.c_int), ("pairs_run", C.c_double), ("kbar_run", C.c_double)]
+
+
+RUN_DTYPE = np.dtype([("evals_run", "i4"), ("pad_", "i4"), ("pairs_run", "f8"), ("kbar_run", "f8")], align=True)
+assert RUN_DTYPE.itemsize == C.sizeof(RunStats)
+# a result record followed by the run statistics of the match (align_batch(..., run_stats=True))
+RESULT_RUN_DTYPE = np.dtype(RESULT_DTYPE.descr + [("evals_run", "i4"), ("pairs_run", "f8"), ("kbar_run", "f8")])
+
+
+def _with_run(res, st):
+    out = np.zeros(len(res), dtype=RESULT_RUN_DTYPE)
+    for k in RESULT_DTYPE.names:
+        out[k] = res[k]
+    for k in ("evals_run", "pairs_run", "kbar_run"):
+        out[k] = st[k]
+    return out
+
+
 def build(force=False):
     so = os.path.join(_HERE, "libndt_oracle.so")
     deps = [os.path.join(_HERE, f) for f in ("ndt_oracle.c", "ndt_oracle_octree.c", "ndt_oracle.h", "Makefile")]
@@ -80,6 +99,13 @@ def lib():
     L.ndt_oracle_align_batch.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int]
     L.ndt_oracle_align_seeds.restype = C.c_int
     L.ndt_oracle_align_seeds.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, C.c_int]
+    L.ndt_oracle_align_ex.restype = C.c_int
+    L.ndt_oracle_align_ex.argtypes = [vp, vp, sz, sz, dp, C.POINTER(Result), vp, C.c_int, C.POINTER(RunStats)]
+    L.ndt_oracle_align_batch_ex.restype = C.c_int
+    L.ndt_oracle_align_batch_ex.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, vp]
+    L.ndt_oracle_align_seeds_ex.restype = C.c_int
+    L.ndt_oracle_align_seeds_ex.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, C.c_int, vp]
+    L.ndt_oracle_set_memoise.argtypes = [C.c_int]
     L.ndt_oracle_fitness.restype = C.c_double
     L.ndt_oracle_fitness.argtypes = [vp, vp, sz, sz, C.c_float, C.c_float, C.c_float, C.c_float]
     L.ndt_oracle_approx_voxel_filter.restype = sz
@@ -148,32 +174,46 @@ class Map:
         s = lib().ndt_oracle_eval_at(self.h, scan.ctypes.data, len(scan), 8, p, g, H, C.byref(pr))
         return s, np.array(g), np.array(H).reshape(3, 3), pr.value
 
-    def align(self, scan, init, trace_cap=0):
+    def align(self, scan, init, trace_cap=0, memoise=False, run_stats=False):
         scan = _f32c(scan)
         r = Result()
+        st = RunStats()
         tr = np.zeros((max(trace_cap, 1), 8)) if trace_cap else None
-        lib().ndt_oracle_align(self.h, scan.ctypes.data, len(scan), 8, (C.c_double * 3)(*init),
-                               C.byref(r), tr.ctypes.data if trace_cap else None, trace_cap)
+        lib().ndt_oracle_set_memoise(1 if memoise else 0)
+        try:
+            lib().ndt_oracle_align_ex(self.h, scan.ctypes.data, len(scan), 8, (C.c_double * 3)(*init),
+                                      C.byref(r), tr.ctypes.data if trace_cap else None, trace_cap, C.byref(st))
+        finally:
+            lib().ndt_oracle_set_memoise(0)
         out = np.frombuffer(bytes(r), dtype=RESULT_DTYPE)[0].copy()
+        if run_stats:
+            out = _with_run(np.array([out]), np.frombuffer(bytes(st), dtype=RUN_DTYPE))[0]
         if trace_cap:
             return out, tr[:min(trace_cap, int(out["flags"]))]
         return out
 
-    def align_batch(self, scans, offsets, inits, nthreads=1, shared_scan=False):
+    def align_batch(self, scans, offsets, inits, nthreads=1, shared_scan=False, memoise=False, run_stats=False):
+        """memoise: a line-search trial at the step length of the pass just run re-uses that pass's totals (what the device
+        path does; same results).  run_stats: records of RESULT_RUN_DTYPE -- the result plus evals_run / pairs_run / kbar_run,
+        the passes and (point, voxel) pairs the DEVICE path runs of the match (kbar_run = the device's ndt_result.kbar)."""
         scans = _f32c(scans)
         offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
         inits = np.ascontiguousarray(inits, dtype=np.float64).reshape(-1, 3)
-        if shared_scan:                       # every initial guess against scan 0
-            B = len(inits)
-            res = np.zeros(B, dtype=RESULT_DTYPE)
-            one = scans[int(offsets[0]):int(offsets[1])]
-            lib().ndt_oracle_align_seeds(self.h, one.ctypes.data, len(one), B, inits.ctypes.data, res.ctypes.data, nthreads)
-            return res
-        B = len(offsets) - 1
+        B = len(inits) if shared_scan else len(offsets) - 1
         res = np.zeros(B, dtype=RESULT_DTYPE)
-        lib().ndt_oracle_align_batch(self.h, scans.ctypes.data, offsets.ctypes.data, B,
-                                     inits.ctypes.data, res.ctypes.data, nthreads)
-        return res
+        st = np.zeros(B, dtype=RUN_DTYPE)
+        lib().ndt_oracle_set_memoise(1 if memoise else 0)
+        try:
+            if shared_scan:                       # every initial guess against scan 0
+                one = scans[int(offsets[0]):int(offsets[1])]
+                lib().ndt_oracle_align_seeds_ex(self.h, one.ctypes.data, len(one), B, inits.ctypes.data, res.ctypes.data,
+                                                nthreads, st.ctypes.data)
+            else:
+                lib().ndt_oracle_align_batch_ex(self.h, scans.ctypes.data, offsets.ctypes.data, B,
+                                                inits.ctypes.data, res.ctypes.data, nthreads, st.ctypes.data)
+        finally:
+            lib().ndt_oracle_set_memoise(0)
+        return _with_run(res, st) if run_stats else res
 
     def fitness(self, scan, c, s, tx, ty):
         scan = _f32c(scan)

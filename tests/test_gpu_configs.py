@@ -51,7 +51,7 @@ def test_c3_full_batch_every_scan_vs_oracle(gpu, oracle, world_1m, stale, preset
     gm = capi.Map(ctx, m, capi.default_params(preset, resolution=cfg["resolution"], stale_h_ang=stale))
     om = oracle.Map(m, oracle.default_params(preset, resolution=cfg["resolution"], stale_h_ang=stale))
     res = gm.align_batch(scans, off, inits)
-    ref = om.align_batch(scans, off, inits, nthreads=NTHREADS)
+    ref = om.align_batch(scans, off, inits, nthreads=NTHREADS, run_stats=True)
     for b in range(256):
         assert_result_parity(res[b], ref[b])
     assert np.array_equal(res["iters"], ref["iters"]) and np.array_equal(res["ref_evals"], ref["ref_evals"])
@@ -74,7 +74,7 @@ def test_c4_2048_scans_one_launch_vs_oracle_and_shards(gpu, oracle, world_1m, st
         assert part.tobytes() == res[lo:hi].tobytes(), "shard %d differs from the 2048-scan launch" % r
     # the oracle on every scan
     om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"], stale_h_ang=stale))
-    ref = om.align_batch(scans, off, inits, nthreads=NTHREADS)
+    ref = om.align_batch(scans, off, inits, nthreads=NTHREADS, run_stats=True)
     for b in range(B):
         assert_result_parity(res[b], ref[b])
     dp = np.abs(res["pose"] - ref["pose"])
@@ -108,7 +108,7 @@ def test_c5_4096_seeds_shared_scan_vs_oracle_and_shards(gpu, oracle, world_5m, s
     for r in range(8):
         part = gm.align_batch(scan, off, seeds[512 * r:512 * (r + 1)], shared_scan=True)
         assert part.tobytes() == res[512 * r:512 * (r + 1)].tobytes(), "seed shard %d" % r
-    ref = om.align_batch(scan, off, seeds, shared_scan=True, nthreads=NTHREADS)
+    ref = om.align_batch(scan, off, seeds, shared_scan=True, nthreads=NTHREADS, run_stats=True)
     for b in range(len(seeds)):
         assert_result_parity(res[b], ref[b])
     # relocalisation: the best hypothesis is the same one and it is the true pose
@@ -136,7 +136,7 @@ def test_hbm_fallback_paths_match_oracle(gpu, oracle, world_5m):
         scan, truth, init = wide.make(k)
         r = gm.align(scan, init)
         assert int(r["flags"]) & capi.FLAG_REGION_CLIPPED, "scan %d was expected not to fit the window" % k
-        assert_result_parity(r, om.align(scan, init))
+        assert_result_parity(r, om.align(scan, init, run_stats=True))
     # (2) poses that start 2-3 m away and walk: the window is staged around the first pose (+ 2 cells around
     # every cell a point fell in), later poses reach voxels outside that set
     near = synth.ScanFactory(m, cfg["half"], cfg["n_scan"], radius=12.0)
@@ -146,7 +146,7 @@ def test_hbm_fallback_paths_match_oracle(gpu, oracle, world_5m):
         far = truth + np.array([2.4 * np.cos(k), 2.4 * np.sin(k), np.radians(4.0 * (k - 2.5))])
         r = gm.align(scan, far)
         n_spill += int((int(r["flags"]) & capi.FLAG_WINDOW_SPILL) != 0)
-        assert_result_parity(r, om.align(scan, far))
+        assert_result_parity(r, om.align(scan, far, run_stats=True))
     assert n_spill > 0, "no window left voxels in HBM: the test does not reach the fall-back"
 
 
@@ -164,17 +164,17 @@ def test_scan_above_the_lds_sort_limit(gpu, oracle, world_1m):
         scan, truth, init = sf.make(3)
         r = gm.align(scan, init)
         assert int(r["flags"]) & capi.FLAG_UNSORTED
-        assert_result_parity(r, om.align(scan, init))
+        assert_result_parity(r, om.align(scan, init, run_stats=True))
     sf = synth.ScanFactory(m, cfg["half"], 15_000, radius=35.0)
     for k in (1, 2):
         scan, truth, init = sf.make(k)
         r = gm.align(scan, init)
         assert not (int(r["flags"]) & capi.FLAG_UNSORTED)
-        assert_result_parity(r, om.align(scan, init))
+        assert_result_parity(r, om.align(scan, init, run_stats=True))
     # a mixed batch: both set-up routines and the unordered path side by side in one launch
     parts = [synth.ScanFactory(m, cfg["half"], n, radius=40.0).make(5)[:3:2] for n in (9_000, 15_000, 10_240, 10_241, 25_000)]
     scans = np.concatenate([p[0] for p in parts]); inits = np.stack([p[1] for p in parts])
     off = np.concatenate([[0], np.cumsum([len(p[0]) for p in parts])]).astype(np.uint64)
     res = gm.align_batch(scans, off, inits)
     for b in range(len(parts)):
-        assert_result_parity(res[b], om.align(parts[b][0], parts[b][1]))
+        assert_result_parity(res[b], om.align(parts[b][0], parts[b][1], run_stats=True))

@@ -99,3 +99,50 @@ def test_match_launches_beside_foreign_queues(hog, B):
     assert max(t_hog) < 50.0 and max(t_quiet) < 50.0
     assert q < 2.0 * a, "an idle stream must not double the launch time"
     del idle_before, idle_after
+
+
+def test_a_launch_that_fails_behind_its_first_kernel_leaves_the_context_ordered():
+    """Error path of ndt_align_batch_dev (round 5): NDT_OPT_INJECT_FAULT makes launch_align return NDT_E_HIP right behind the
+    dispatch of the match kernel.  That kernel is queued and uses the context's scratch (control words, ordered copies), so
+    the failing call must still close its scratch bracket: the next call on ANOTHER stream is ordered behind the orphan --
+    without that its memset of the control words lands under a running persistent kernel.  The failed launch is also entered
+    in the ring and in the map's readers: ndt_ctx_wait_launch finds it."""
+    import torch
+    from ndt_slam_amd import capi, synth
+    dev = torch.device("cuda", 0)
+    cfg = synth.CONFIGS["C3"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    B = 256
+    scans, off, _, inits = sf.batch(0, B)
+    ctx = capi.Context(0)
+    s_a, s_b = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    ctx.set_stream(s_a.cuda_stream)
+    gm = capi.Map(ctx, m, capi.default_params(resolution=cfg["resolution"]))
+    d_sc = torch.from_numpy(scans).to(dev); d_off = torch.from_numpy(off.astype(np.int64)).to(dev)
+    d_in = torch.from_numpy(inits).to(dev)
+    d_ref = torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev)
+    d_junk, d_res = torch.zeros_like(d_ref), torch.zeros_like(d_ref)
+    args = (d_sc.data_ptr(), d_off.data_ptr(), B, len(scans), d_in.data_ptr())
+    gm.align_batch_dev(*args, d_ref.data_ptr(), stream=s_a.cuda_stream)
+    torch.cuda.synchronize()
+    ref = d_ref.cpu().numpy().tobytes()
+    assert np.all(np.frombuffer(ref, dtype=capi.RESULT_DTYPE)["status"] == 0)
+    for rnd in range(5):
+        ctx.set_option(capi.OPT_INJECT_FAULT, 1)
+        with pytest.raises(capi.NdtError, match="injected fault"):
+            gm.align_batch_dev(*args, d_junk.data_ptr(), stream=s_a.cuda_stream)
+        # at once, on another stream, with the same context: ordered behind the orphan kernel on s_a
+        gm.align_batch_dev(*args, d_res.data_ptr(), stream=s_b.cuda_stream)
+        ctx.wait_launch(1, s_b.cuda_stream)                   # the failed launch has a place in the ring
+        s_b.synchronize()
+        got = d_res.cpu().numpy().tobytes()
+        assert got == ref, "round %d: records differ after a failed launch" % rnd
+        # the orphan ran to its end (its records are the matches without a fitness score: the fitness kernels were not queued)
+        s_a.synchronize()
+        junk = np.frombuffer(d_junk.cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
+        full = np.frombuffer(ref, dtype=capi.RESULT_DTYPE)
+        assert np.all(junk["status"] == 0) and np.array_equal(junk["T03"], full["T03"]) and np.all(junk["fitness"] > 1e300)
+    # a two-phase rebuild that has to be queued again waits for a failed launch like for any other reader
+    ctx.set_option(capi.OPT_INJECT_FAULT, 0)
+    gm.close(); ctx.close()
