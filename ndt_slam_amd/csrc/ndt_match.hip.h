@@ -152,6 +152,16 @@ __device__ __forceinline__ void st_wt_f2(float2 *p, float2 v) {
   asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
 }
 
+// A workgroup barrier that orders LDS traffic only: __syncthreads() carries workgroup-scope fences over ALL memory, i.e. an
+// s_waitcnt vmcnt(0) in front of the barrier -- every global load or store a wave still has in flight is waited for right there.
+// The set-up phases keep loads in flight across their LDS barriers on purpose (the records' lines asked for early, the
+// ordered copy's stores draining); their barriers fence the `local` address space alone: s_waitcnt lgkmcnt(0) + s_barrier.
+__device__ __forceinline__ void sync_lds() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // min / max over the 64 lanes with DPP moves (row shifts, then the rows' results carried along): valid in lane 63
 __device__ __forceinline__ int wave_min_dpp(int x) {
 #define NDT_DPP_MIN(CTRL, ROWS) { const int t_ = __builtin_amdgcn_update_dpp(x, x, CTRL, ROWS, 0xF, false); x = t_ < x ? t_ : x; }
@@ -293,14 +303,21 @@ __device__ __noinline__ void compute_region(const MapView &M, const Tf32 &T0, co
 // LDS record (centroid -inf).  Sets L.RG.nspill = occupied voxels left without a record.
 // Cells are walked 1024 at a time with consecutive lanes on consecutive cells (coalesced centroid
 // and record reads); the row-major numbering comes from wave ballots kept in LDS.
-__device__ __noinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool, u64 *stamps = nullptr, u64 t0s = 0) {
+//
+// Two routines: fill_window_plan works out WHICH voxels get a record -- occupancy words, dilation of the marked cells, the
+// prefix sums that number them -- and touches only the control block (L.wpart, L.wtmp, L.swave, L.sbox); fill_window_fetch
+// writes the slot table and fetches the records into the pool.  (Round 5 tried the plan in the middle of the owner's ordering
+// phases with the records' lines asked for at once, so that the fetch would find them in L2: no gain -- the fetch was
+// bound by its own LDS instructions and address arithmetic, not by the loads, which arrive while the slot table is
+// written; LOG R5.1.)
+__device__ __forceinline__ int window_rounds(const Region &r) { return (r.rw * r.rh + kBlock - 1) / kBlock; }   // <= kRegionCells / kBlock = 16
+
+__device__ __noinline__ void fill_window_plan(const MapView &M, Lds &L, u64 *stamps = nullptr, u64 t0s = 0) {
   const Region r = L.RG;
   const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
-  unsigned short *slot = reinterpret_cast<unsigned short *>(pool);
-  CellEntry *ent = reinterpret_cast<CellEntry *>(reinterpret_cast<char *>(pool) + ((r.rw * r.rh * 2 + 15) / 16) * 16);
   const u64 t_fill0 = kProf ? wall_clock64() : 0;
   const int ncell = r.rw * r.rh;
-  const int rounds = (ncell + kBlock - 1) / kBlock;          // <= kRegionCells / kBlock = 16
+  const int rounds = window_rounds(r);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   u64 *keepw = reinterpret_cast<u64 *>(L.wpart) + 256;        // [rounds][kWaves] ballots (wmap uses the first 2 KiB)
   u64 *occw = keepw + 256;
@@ -388,77 +405,97 @@ __device__ __noinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool, 
   if (threadIdx.x == 0) {
     const int kept = L.swave[0] + L.swave[1] + L.swave[2] + L.swave[3];
     const int skipped = L.sbox[0] + L.sbox[1] + L.sbox[2] + L.sbox[3];
-    CellEntry z; z.cent = make_float2(INFINITY, INFINITY); z.mx = z.my = z.i00 = z.i01 = z.i11 = 0.0;
-    ent[r.cap] = z;                             // voxels outside the search set
-    z.cent = make_float2(-INFINITY, -INFINITY);
-    ent[r.cap + 1] = z;                         // occupied voxels without an LDS record
     L.RG.nspill = skipped + (kept > r.cap ? kept - r.cap : 0);
     if (kProf) L.diag[1] = (unsigned)(wall_clock64() - t_fill0);
   }
   __syncthreads();
   NDT_STAMP(stamps, t0s, 9);
-  // slot table: every cell of the window (no global memory involved)
-  for (int j = 0; j < rounds; ++j) {
-    const int c = j * kBlock + threadIdx.x;
-    if (c >= ncell) break;
-    const u64 kb = keepw[j * kWaves + wave], ob = occw[j * kWaves + wave];
-    unsigned sl = (unsigned)r.cap;
-    if ((ob >> lane) & 1ull) {
-      sl = (unsigned)r.cap + 1u;
-      if ((kb >> lane) & 1ull) {
-        const int next = base[j * kWaves + wave] + __builtin_popcountll(kb & ((1ull << lane) - 1ull));
-        if (next < r.cap) sl = (unsigned)next;
-      }
-    }
-    slot[c] = (unsigned short)sl;
+}
+
+constexpr int kRecPer = 4;
+static_assert(kPoolBytes / (int)sizeof(CellEntry) <= kRecPer * kBlock, "a thread fetches at most kRecPer records");
+
+// Round 5.  Until round 4: sixteen rounds of one cell per thread for the slot table (a 2-byte LDS store per cell: the LDS pipe
+// takes one instruction per ~5 cycles whatever its width -- 3.3 us), and every record's cell found from its number by a binary
+// search over the prefix sums + a search for the n-th set bit (eight dependent LDS reads and ~100 instructions per record:
+// 2.2 us).  Now a thread takes EIGHT consecutive cells -- one byte of each ballot word, their eight slot numbers counted up in
+// registers, one 16-byte store -- and leaves the padded-grid index of every cell that gets a record in the first word of that
+// record's own place; the record-major pass (all of a thread's loads in flight together, as before) reads its cells from there.
+__device__ __noinline__ void fill_window_fetch(const MapView &M, Lds &L, uint4 *pool, u64 *stamps = nullptr, u64 t0s = 0) {
+  const Region r = L.RG;
+  uint4 *slot8 = pool;                                   // the slot table, eight 16-bit entries per 16-byte word
+  CellEntry *ent = reinterpret_cast<CellEntry *>(reinterpret_cast<char *>(pool) + ((r.rw * r.rh * 2 + 15) / 16) * 16);
+  const int ncell = r.rw * r.rh;
+  const u64 *keepw = reinterpret_cast<const u64 *>(L.wpart) + 256;
+  const u64 *occw = keepw + 256;
+  const int *base = reinterpret_cast<const int *>(L.wtmp);
+  if (threadIdx.x == 0) {
+    CellEntry z; z.cent = make_float2(INFINITY, INFINITY); z.mx = z.my = z.i00 = z.i01 = z.i11 = 0.0;
+    ent[r.cap] = z;                             // voxels outside the search set
+    z.cent = make_float2(-INFINITY, -INFINITY);
+    ent[r.cap + 1] = z;                         // occupied voxels without an LDS record
   }
-  // records: thread t fetches records t, t + 1024, ... (at most kRecPer) -- the cell of record number k is found
-  // from the prefix sums (which ballot word, which set bit), so that ALL of a thread's loads are in flight together
+  const int rw1 = max(r.rw, 1);
+  for (int g = threadIdx.x; 8 * g < ncell; g += kBlock) {               // at most kRegionCells / 8 / kBlock = 2 rounds
+    const int w = g >> 3, sh = (g & 7) << 3;
+    const u64 kw = keepw[w], ow = occw[w];                              // (bits of cells >= ncell are zero: fill_window_plan)
+    const unsigned kb = (unsigned)(kw >> sh) & 0xFFu, ob = (unsigned)(ow >> sh) & 0xFFu;
+    int next = base[w] + __builtin_popcountll(kw & ((1ull << sh) - 1ull));
+    const int c0 = 8 * g;
+    int ly = c0 / rw1, lx = c0 - ly * rw1;
+    unsigned sl[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      unsigned v = (unsigned)r.cap;
+      if ((ob >> i) & 1u) {
+        v = (unsigned)r.cap + 1u;
+        if ((kb >> i) & 1u) {
+          if (next < r.cap) {
+            v = (unsigned)next;
+            // this record's cell in the padded grid, left in the record's own place until the record arrives
+            *reinterpret_cast<unsigned *>(ent + next) = (unsigned)((size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2));
+          }
+          ++next;
+        }
+      }
+      sl[i] = v;
+      if (++lx == r.rw) { lx = 0; ++ly; }
+    }
+    slot8[g] = make_uint4(sl[0] | (sl[1] << 16), sl[2] | (sl[3] << 16), sl[4] | (sl[5] << 16), sl[6] | (sl[7] << 16));
+  }
+  sync_lds();
+  NDT_STAMP(stamps, t0s, 14);
+  // records: thread t fetches records t, t + 1024, ... (at most kRecPer), ALL of its loads in flight together
   // (walking the cells round by round, four rounds of loads at a time, took 14 us: four dependent latencies)
-  {
-    constexpr int kRecPer = 4;
-    const int kept = min(L.swave[0] + L.swave[1] + L.swave[2] + L.swave[3], r.cap);
-    static_assert(kPoolBytes / (int)sizeof(CellEntry) <= kRecPer * kBlock, "a thread fetches at most kRecPer records");
-    int nx[kRecPer]; double2 ra[kRecPer], rb[kRecPer], rc[kRecPer];     // rc.y: the float32 centroid (map_build: write_voxel)
+  const int kept = min(L.swave[0] + L.swave[1] + L.swave[2] + L.swave[3], r.cap);
+  int nx[kRecPer]; double2 ra[kRecPer], rb[kRecPer], rc[kRecPer];     // rc.y: the float32 centroid (map_build: write_voxel)
 #pragma unroll
-    for (int u = 0; u < kRecPer; ++u) {
-      const int k = (int)threadIdx.x + u * kBlock;
-      nx[u] = -1;
-      if (k < kept) {
-        int lo = 0, hi = nword - 1;                          // last ballot word whose exclusive prefix is <= k
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-          const int mid = (lo + hi + 1) >> 1;
-          if (base[mid] <= k) lo = mid; else hi = mid - 1;
-        }
-        u64 v = keepw[lo];
-        int nth = k - base[lo], pos = 0;                     // the nth set bit of v (0-based)
-#pragma unroll
-        for (int sh = 32; sh >= 1; sh >>= 1) {
-          const u64 lowmask = (1ull << sh) - 1ull;
-          const int cnt = __builtin_popcountll(v & lowmask);
-          if (nth >= cnt) { nth -= cnt; v >>= sh; pos += sh; } else { v &= lowmask; }
-        }
-        const int c = lo * 64 + pos;
-        const int ly = c / r.rw, lx = c - ly * r.rw;
-        const size_t pg = (size_t)(r.y0 + ly + 2) * M.gw + (r.x0 + lx + 2);
-        const double *rec = M.rec + pg * 8;
-        ra[u] = *reinterpret_cast<const double2 *>(rec); rb[u] = *reinterpret_cast<const double2 *>(rec + 2);
-        rc[u] = *reinterpret_cast<const double2 *>(rec + 4);
-        nx[u] = k;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kRecPer; ++u) {
-      if (nx[u] >= 0) {
-        const u64 cb = (u64)__double_as_longlong(rc[u].y);
-        CellEntry E; E.cent = make_float2(__uint_as_float((unsigned)cb), __uint_as_float((unsigned)(cb >> 32)));
-        E.mx = ra[u].x; E.my = ra[u].y; E.i00 = rb[u].x; E.i01 = rb[u].y; E.i11 = rc[u].x;
-        ent[nx[u]] = E;
-      }
+  for (int u = 0; u < kRecPer; ++u) {
+    const int k = (int)threadIdx.x + u * kBlock;
+    nx[u] = -1;
+    if (k < kept) {
+      const size_t pg = *reinterpret_cast<const unsigned *>(ent + k);
+      const double *rec = M.rec + pg * 8;
+      ra[u] = gld_d2(rec); rb[u] = gld_d2(rec + 2); rc[u] = gld_d2(rec + 4);
+      nx[u] = k;
     }
   }
-  __syncthreads();
+  NDT_STAMP(stamps, t0s, 15);
+#pragma unroll
+  for (int u = 0; u < kRecPer; ++u) {
+    if (nx[u] >= 0) {
+      const u64 cb = (u64)__double_as_longlong(rc[u].y);
+      CellEntry E; E.cent = make_float2(__uint_as_float((unsigned)cb), __uint_as_float((unsigned)(cb >> 32)));
+      E.mx = ra[u].x; E.my = ra[u].y; E.i00 = rb[u].x; E.i01 = rb[u].y; E.i11 = rc[u].x;
+      ent[nx[u]] = E;
+    }
+  }
+  __syncthreads();                                 // (all memory: whatever this workgroup stored before is drained here too -- the late publication relies on it)
+}
+
+__device__ __forceinline__ void fill_window(const MapView &M, Lds &L, uint4 *pool, u64 *stamps = nullptr, u64 t0s = 0) {
+  fill_window_plan(M, L, stamps, t0s);
+  fill_window_fetch(M, L, pool, stamps, t0s);
 }
 
 // Owner: spatial order of the scan.  The points are sorted by the window cell they fall in at the
@@ -581,13 +618,26 @@ __device__ __noinline__ bool sort_points(const MapView &M, const Tf32 &T0, const
 // routines read the scan from memory four times -- bounding box, histogram, scatter, and a gather by point number in the
 // ranking phase, a few loads in flight each, every round a trip to L2 -- and every phase was a chain of dependent LDS
 // round trips between two barriers: 33 us of the 50 us a scan's set-up took.  Here every thread loads its PER points
-// once (all loads in flight; the counters are cleared and lane 0 sets the optimiser state up while they travel), every
-// thread derives the window geometry itself (no broadcast through LDS), a thread's run of cell counters is read into
-// registers once for both the marked-cell bitmap and the offsets, and in the last phase each thread ranks ITS OWN points
-// inside their cells -- the PER searches interleaved, so that their LDS reads pipeline -- and stores them from the
-// registers: no gather.  Same order as sort_points (window cell, then input order), same bitmap.
+// once (all loads in flight; the counters are cleared and two lanes form the float32 matrix of the first pose while they
+// travel), a thread's run of cell counters is read into registers once for both the marked-cell bitmap and the offsets, and
+// every point goes from its register to its place in an LDS image of the ordered copy: no gather.
+//
+// Round 5 -- the order inside a cell.  It only has to be the SAME whatever the scheduling.  Rounds 3-4 kept the input order
+// and paid for it by COUNTING: every entry its rank among the entries of its cell, 8 us of a 40-us set-up.  Now it is
+// (wave, round, lane) of the thread that holds the point -- the order in which the scatter hands the places out when the
+// waves take their turns one after the other: a wave's PER atomics on a cell counter are issued in round order and the LDS
+// executes one wave's instructions in order; between the lanes of ONE instruction that hit the same counter the LDS serialises
+// -- in lane order on this hardware, which the ISA does not promise, so every entry carries its sequence number and the order
+// that came out is checked (one comparison per entry: the entries of the whole array must ascend); if it ever does not, the
+// places are found by counting after all.  The turns are sixteen LDS-only barriers, 3.3 us (a token in LDS that the waves
+// poll for their turn: 6 us).  Results differ from rounds 3-4 in the last bits of the sums (other order inside the cells), not
+// in the float32 transforms or the iteration counts (every parity test, all configurations).
+// The barriers of these phases order LDS traffic only (sync_lds): the ordered copy's stores to memory drain behind them.
+#ifndef NDT_ORDER_INLINE
+#define NDT_ORDER_INLINE __noinline__
+#endif
 template <bool SSE, int PER>
-__device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &P, const double *__restrict__ init,
+__device__ NDT_ORDER_INLINE void order_scan_regs(const MapView &M, const OptParams &P, const double *__restrict__ init,
                                              const float2 *__restrict__ scan, int n, Lds &L, uint4 *pool,
                                              float2 *__restrict__ sp, u64 *stamps = nullptr, u64 t0s = 0) {
   // The LDS pipe takes one wave instruction every ~4 cycles whatever its width (tools/repro/rates.hip), and these phases
@@ -595,26 +645,30 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
   constexpr int kRun = 20;                                             // counters per thread: five 16-byte words
   constexpr int kHistWords = (kRegionCells + 1 + 3) & ~3;              // ncell + 1 counters (last: outside the window), padded
   static_assert(kRun * kBlock >= kHistWords && kRun % 4 == 0, "every counter belongs to a thread's run");
-  // the optimiser's start first, while nothing else is live (round 4: called behind the loads it made this routine spill its
-  // twenty point registers around the call once init_state had grown by Eigen's rotation() -- 192 instead of 96 bytes of
-  // scratch per lane and 1.7 % on the whole kernel; the scan's first touch is long enough without it)
+  const int wv = (int)(threadIdx.x >> 6), ln = (int)(threadIdx.x & 63);
+  // the optimiser's start first, while nothing else is live: one lane, ~5 us of dependent scalar code (Eigen's rotation() of the
+  // first pose the bulk of it).  The other waves' loads are on their way meanwhile; wave 0 asks for its points behind it (a
+  // call in front of which loads are in flight waits for them).  Round 5 tried the long part on the last wave beside the
+  // scatter's turns, and all of it inlined behind the loads: slower both ways -- this phase is the 20 MB of scans that
+  // the 256 workgroups of a launch ask for at the same moment, not the scalar code (LOG R5.1).
   if (threadIdx.x == 0) init_state(L.S, P, init, (double)n);
   float2 pt[PER];
 #pragma unroll
   for (int u = 0; u < PER; ++u) pt[u] = gld_f2(scan + min((int)threadIdx.x + u * kBlock, n - 1));
-  // ... while the first touch of the scan is on its way
+  // ... while the first touch of the scan is on its way: cleared counters
   unsigned *wmap = reinterpret_cast<unsigned *>(L.wpart);
   unsigned *hist = reinterpret_cast<unsigned *>(pool);
-  unsigned *idx = hist + kHistWords;                                   // n entries (cell << 15 | point number)
-  unsigned *inv = idx + kSortRegs;                                     // place of point i in the ordered copy
+  unsigned *idx = hist + kHistWords;                                   // n entries (cell << 15 | sequence number)
+  unsigned *inv = idx + kSortRegs;                                     // (repair only) place of the point with sequence number q
 #pragma unroll
   for (int k = 0; k < (kHistWords / 4 + kBlock - 1) / kBlock; ++k) {
     const int i = (int)threadIdx.x + k * kBlock;
     if (i < kHistWords / 4) pool[i] = make_uint4(0u, 0u, 0u, 0u);
   }
   if (threadIdx.x < kRegionCells / 32) wmap[threadIdx.x] = 0u;
-  if (threadIdx.x == 0) {
+  if (threadIdx.x == 64) {
     L.sbox[0] = INT_MAX; L.sbox[1] = INT_MAX; L.sbox[2] = INT_MIN; L.sbox[3] = INT_MIN;
+    L.sflag[0] = 0;                                                    // raised when the scatter's order has to be repaired
   }
   __syncthreads();
   NDT_STAMP(stamps, t0s, 0);
@@ -639,7 +693,7 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
       }
     }
     mnx = wave_min_dpp(mnx); mny = wave_min_dpp(mny); mxx = wave_max_dpp(mxx); mxy = wave_max_dpp(mxy);
-    if ((threadIdx.x & 63) == 63 && mnx <= mxx) {
+    if (ln == 63 && mnx <= mxx) {
       atomicMin(&L.sbox[0], mnx); atomicMin(&L.sbox[1], mny); atomicMax(&L.sbox[2], mxx); atomicMax(&L.sbox[3], mxy);
     }
   }
@@ -661,7 +715,7 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
       atomicAdd(&hist[key[u]], 1u);
     }
   }
-  __syncthreads();
+  sync_lds();
   NDT_STAMP(stamps, t0s, 2);
   // A thread's run of kRun counters, read once (counters past ncell are zero): its bits of the marked-cell bitmap (the
   // run touches at most two words) and its part of the exclusive scan (DPP scan over the wave, the waves' totals through LDS).
@@ -681,10 +735,10 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
     if ((unsigned)bits) atomicOr(&wmap[c0 >> 5], (unsigned)bits);
     if ((unsigned)(bits >> 32)) atomicOr(&wmap[(c0 >> 5) + 1], (unsigned)(bits >> 32));
     const unsigned incl = wave_incl_scan(mine);
-    if ((threadIdx.x & 63) == 63) L.swave[threadIdx.x >> 6] = (int)incl;
-    __syncthreads();
+    if (ln == 63) L.swave[wv] = (int)incl;
+    sync_lds();
     unsigned run = incl - mine;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += (unsigned)L.swave[w];
+    for (int w = 0; w < wv; ++w) run += (unsigned)L.swave[w];
     if (live) {
 #pragma unroll
       for (int k = 0; k < kRun / 4; ++k) {
@@ -694,21 +748,40 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
       }
     }
   }
-  __syncthreads();
+  sync_lds();
   NDT_STAMP(stamps, t0s, 3);
-  // scatter (cell, point number) packed in one word; afterwards hist[c] = end of cell c
+  // Places: the waves in turn (see the head of the routine).
+  unsigned place[PER];
+  for (int w = 0; w < kWaves; ++w) {
+    if (wv == w) {
+#pragma unroll
+      for (int u = 0; u < PER; ++u) place[u] = key[u] >= 0 ? atomicAdd(&hist[key[u]], 1u) : 0u;
+    }
+    sync_lds();                                                        // (the returns are in: the next wave's atomics come behind)
+  }
 #pragma unroll
   for (int u = 0; u < PER; ++u)
-    if (key[u] >= 0) idx[atomicAdd(&hist[key[u]], 1u)] = ((unsigned)key[u] << 15) | (unsigned)((int)threadIdx.x + u * kBlock);
-  __syncthreads();
+    if (key[u] >= 0) idx[place[u]] = ((unsigned)key[u] << 15) | (unsigned)((wv * PER + u) * 64 + ln);
+  sync_lds();
   NDT_STAMP(stamps, t0s, 4);
-  // Input order inside a cell (the atomics above arrive in any order).  Ranking is done by POSITION -- consecutive lanes
-  // on consecutive entries, i.e. mostly on the same cell: equal trip counts, broadcast reads (by point, a wave's 64
-  // random points made every lane wait for the densest cell among them: 23 us) -- four entries of the cell per LDS read.
-  // The place of point i goes to inv[i]; the thread that holds point i in a register puts it there in an LDS image of
-  // the ordered copy (the counters and entries are dead by then), which goes to memory in coalesced 16-byte stores:
-  // no gather from memory, no scattered 8-byte stores (10k of those per workgroup took 13 us to drain).
   {
+    bool bad = false;
+    unsigned va[PER], vb[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {                                    // all in flight
+      const int j = (int)threadIdx.x + u * kBlock;
+      va[u] = idx[min(j, n - 1)]; vb[u] = idx[min(j + 1, n - 1)];
+    }
+#pragma unroll
+    for (int u = 0; u < PER; ++u) bad |= ((int)threadIdx.x + u * kBlock + 1 < n) && !(va[u] < vb[u]);
+    if (__ballot(bad) != 0ull && ln == 0) L.sflag[0] = 1;              // (raised by any wave)
+  }
+  sync_lds();
+  NDT_STAMP(stamps, t0s, 11);
+  if (L.sflag[0]) {
+    // not in sequence: every entry finds its rank among the entries of its cell by counting (consecutive lanes on consecutive
+    // entries, i.e. mostly on the same cell: equal trip counts, broadcast reads, four entries of the cell per LDS read);
+    // hist[c] = end of cell c by now.  The place of the point with sequence number q goes to inv[q].
     const uint4 *idx4 = reinterpret_cast<const uint4 *>(idx);
     unsigned v[PER]; int s0[PER], s1[PER];
 #pragma unroll
@@ -733,32 +806,35 @@ __device__ __noinline__ void order_scan_regs(const MapView &M, const OptParams &
       }
       if (s1[u] > s0[u]) inv[v[u] & 0x7FFFu] = (unsigned)(s0[u] + rank);
     }
-  }
-  NDT_STAMP(stamps, t0s, 11);
-  __syncthreads();
-  NDT_STAMP(stamps, t0s, 12);
-  unsigned place[PER];
+    sync_lds();
 #pragma unroll
-  for (int u = 0; u < PER; ++u) place[u] = key[u] >= 0 ? inv[(int)threadIdx.x + u * kBlock] : 0u;
+    for (int u = 0; u < PER; ++u) place[u] = key[u] >= 0 ? inv[(wv * PER + u) * 64 + ln] : 0u;
+    sync_lds();
+  }
   float2 *stage = reinterpret_cast<float2 *>(pool);                    // n points over the dead counters and entries
   static_assert(kSortRegs * 8 <= (kHistWords + kSortRegs) * 4, "the LDS image of the ordered copy must not reach the places");
 #pragma unroll
   for (int u = 0; u < PER; ++u) if (key[u] >= 0) stage[place[u]] = pt[u];
-  __syncthreads();
-  NDT_STAMP(stamps, t0s, 13);
-  {
-    const float4 *st4 = reinterpret_cast<const float4 *>(pool);
-    float4 *sp4 = reinterpret_cast<float4 *>(sp);                      // (scratch slots start at even point numbers? see below)
-    const bool aligned = (reinterpret_cast<size_t>(sp) & 15) == 0;
-    // write-through: helpers on other XCDs read this copy (see the publishing step in the kernel)
-    if (aligned) {
-      for (int i = threadIdx.x; i < n / 2; i += kBlock) st_wt_f4(sp4 + i, st4[i]);
-      if (threadIdx.x == 0 && (n & 1)) st_wt_f2(sp + (n - 1), stage[n - 1]);
-    } else {
-      for (int i = threadIdx.x; i < n; i += kBlock) st_wt_f2(sp + i, stage[i]);
-    }
+  sync_lds();                                      // the image is complete: copy_out_ordered sends it to memory
+}
+
+// The LDS image of the ordered copy (order_scan_regs) to the scratch copy in memory, in coalesced 16-byte stores,
+// write-through: helpers on other XCDs read this copy (the publishing step drains the stores).  A routine of its own, and a
+// small one (round 5): a routine that keeps values in callee-saved registers reloads them behind an s_waitcnt vmcnt(0) on its
+// way out -- inside order_scan_regs that wait sat right behind these stores and held the workgroup until all 80 KB had
+// landed (2-4 us).  Issued from here, the stores drain while the window's slot table is written.
+__device__ __noinline__ void copy_out_ordered(const uint4 *pool, float2 *__restrict__ sp, int n) {
+  const float4 *st4 = reinterpret_cast<const float4 *>(pool);
+  const float2 *stage = reinterpret_cast<const float2 *>(pool);
+  float4 *sp4 = reinterpret_cast<float4 *>(sp);
+  const bool aligned = (reinterpret_cast<size_t>(sp) & 15) == 0;
+  if (aligned) {
+    for (int i = threadIdx.x; i < n / 2; i += kBlock) st_wt_f4(sp4 + i, st4[i]);
+    if (threadIdx.x == 0 && (n & 1)) st_wt_f2(sp + (n - 1), stage[n - 1]);
+  } else {
+    for (int i = threadIdx.x; i < n; i += kBlock) st_wt_f2(sp + i, stage[i]);
   }
-  __syncthreads();
+  sync_lds();                                      // (the image has been read: the pool is the window's from here on)
 }
 
 // Sum of 12 per-lane values over the 64 lanes of a wave in a fixed order: a butterfly in which every exchange also
@@ -1060,23 +1136,32 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       if (kProf && q1 == 0) q1 = wall_clock64();
       NDT_STAMP(stamps, t0s, 5);
       const u64 q2 = kProf ? wall_clock64() : 0;
+      // Which voxels get a record (control block only; its loads of the map's occupancy words are in front of the copy's
+      // stores: a wait for a load is a wait for every store issued before it), then the ordered copy on its way to memory.
+      fill_window_plan(L.M, L, stamps, t0s);
+      if (reg_path) copy_out_ordered(pool, sp, n);
       if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
         const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
         unsigned *gw = wantmap + (size_t)b * (kRegionCells / 32);
         for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) st32(&gw[i], wmap[i]);
       }
-      if (allow_helpers) {
-        // publish geometry + marked cells + ordered copy before staging the own window, so that idle
-        // workgroups stage theirs meanwhile.  Everything a helper will read is stored write-through (geometry and
-        // marked cells here, the ordered copy in order_scan_regs) and drained by every wave, so the scan is opened
-        // without an agent-scope release -- a write-back of this XCD's whole L2, 3-4 us on the critical path of every
-        // scan.  Scans ordered by the streaming routines (plain stores) keep the release.
-        if (threadIdx.x == 0) {
-          const Region r = L.RG;
-          st32((u32 *)&C->region[0], (u32)r.x0); st32((u32 *)&C->region[1], (u32)r.y0); st32((u32 *)&C->region[2], (u32)r.rw);
-          st32((u32 *)&C->region[3], (u32)r.rh); st32((u32 *)&C->region[4], (u32)r.cap); st32((u32 *)&C->region[5], (u32)r.nspill);
-          st32(&C->use_sorted, (pts != scan) ? 1u : 0u);
-        }
+      // Publication: geometry + marked cells + ordered copy.  Everything a helper will read is stored write-through (geometry
+      // and marked cells here, the ordered copy above) and drained by every wave before the ticket is written, so
+      // the scan is opened without an agent-scope release -- a write-back of this XCD's whole L2, 3-4 us on the critical path of
+      // every scan.  Scans ordered by the streaming routines (plain stores) keep the release.
+      //   * a launch with idle workgroups from the start (fewer scans than workgroups: one scan at a time) publishes BEFORE
+      //     staging the own window, so that the others stage theirs meanwhile;
+      //   * a launch with a scan for every workgroup has nobody to publish to yet: the ticket is written BEHIND the window's
+      //     staging, whose last barrier has drained the stores anyway -- the 2 us of waiting for the copy's 80 KB to land
+      //     go by while the slot table is written (round 5).
+      const bool late_publish = reg_path && B >= (int)gridDim.x;
+      if (allow_helpers && threadIdx.x == 0) {
+        const Region r = L.RG;
+        st32((u32 *)&C->region[0], (u32)r.x0); st32((u32 *)&C->region[1], (u32)r.y0); st32((u32 *)&C->region[2], (u32)r.rw);
+        st32((u32 *)&C->region[3], (u32)r.rh); st32((u32 *)&C->region[4], (u32)r.cap); st32((u32 *)&C->region[5], (u32)r.nspill);
+        st32(&C->use_sorted, (pts != scan) ? 1u : 0u);
+      }
+      if (allow_helpers && !late_publish) {
         drain_vmem();
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1088,7 +1173,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         }
       }
       NDT_STAMP(stamps, t0s, 6);
-      fill_window(L.M, L, pool, stamps, t0s);
+      fill_window_fetch(L.M, L, pool, stamps, t0s);         // (its last barrier waits for every wave's outstanding stores)
+      if (allow_helpers && late_publish && threadIdx.x == 0) st64(&C->ticket, (u64)1 << 32);
       NDT_STAMP(stamps, t0s, 10);
       const u64 q3 = kProf ? wall_clock64() : 0;
       if (kProf && prof && threadIdx.x == 0) {

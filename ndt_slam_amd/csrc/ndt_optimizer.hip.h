@@ -308,16 +308,32 @@ __device__ __forceinline__ void advance(AlignState &S, const OptParams &P, const
   }
 }
 
-__device__ __noinline__ void init_state(AlignState &S, const OptParams &P, const double init[3],
-                                        double n_points) {
+// The optimiser's start in two pieces: the float32 matrix of the initial guess (init_matrix; per lane: 0 the cosine and the
+// translation, 1 the sine -- same code, other argument, as trial_transforms does for every trial) and everything else
+// (init_rest: Eigen's rotation().eulerAngles of that matrix -- a float32 two-sided Jacobi SVD, a couple of thousand dependent
+// instructions -- and the fp64 angle terms).  The owner runs both on one lane at the head of its set-up (init_state).
+__device__ __noinline__ void init_matrix(AlignState &S, const OptParams &P, const double init[3], int lane) {
+  // init_guess = Translation3f * AngleAxisf (src/PoseEstimator.cpp:22-24)
+  const float yaw = (float)init[2];
+  if (P.libm_f32) {
+    const float v = sincosf_glibc(yaw, lane == 0 ? 1 : 0);
+    if (lane == 0) S.T.c = v; else S.T.s = v;
+  } else {
+    double sd, cd;
+    sincos_small((double)yaw, sd, cd);
+    if (lane == 0) S.T.c = (float)cd; else S.T.s = (float)sd;
+  }
+  if (lane == 0) { S.T.tx = (float)init[0]; S.T.ty = (float)init[1]; }
+}
+
+__device__ __noinline__ void init_rest(AlignState &S, const OptParams &P, double n_points) {
   S.iters = 0; S.evals = 0; S.ref_evals = 0; S.converged = 0; S.step_iterations = 0;
   S.open_interval = 1; S.interval_converged = 0; S.pairs = 0.0; S.n_points = n_points;
-  double pi[3] = {init[0], init[1], init[2]};
-  S.T = tf_from_p(pi, P.libm_f32);     // init_guess = Translation3f * AngleAxisf (src/PoseEstimator.cpp:22-24)
+  const Tf32 T = S.T;
   // p0 = (translation, rotation().eulerAngles(0,1,2)) of the float matrix: (-0, 0, yaw) -- the yaw as Eigen and the platform's
   // atan2f compute it (libm_f32: ndt_libm_f32.hip.h) or modelled as atan2f(s, c) correctly rounded
-  S.p[0] = (double)S.T.tx; S.p[1] = (double)S.T.ty;
-  S.p[2] = P.libm_f32 ? (double)eigen_init_yaw(S.T.c, S.T.s) : (double)(float)atan2((double)S.T.s, (double)S.T.c);
+  S.p[0] = (double)T.tx; S.p[1] = (double)T.ty;
+  S.p[2] = P.libm_f32 ? (double)eigen_init_yaw(T.c, T.s) : (double)(float)atan2((double)T.s, (double)T.c);
   S.xt[0] = S.p[0]; S.xt[1] = S.p[1]; S.xt[2] = S.p[2];
   S.dir[0] = S.dir[1] = S.dir[2] = 0.0; S.a_t = 0.0;
   angle_cs(P.snap_thresh, S.p[2], S.cj, S.sj);
@@ -325,6 +341,14 @@ __device__ __noinline__ void init_state(AlignState &S, const OptParams &P, const
   S.score = 0.0;
   S.need_tf = 0;
   S.phase = PH_INIT;
+}
+
+
+// both on one lane (scans that do not take the register-resident set-up)
+__device__ __forceinline__ void init_state(AlignState &S, const OptParams &P, const double init[3], double n_points) {
+  init_matrix(S, P, init, 0);
+  init_matrix(S, P, init, 1);
+  init_rest(S, P, n_points);
 }
 
 // a9: src/PoseEstimator.cpp:31-35 on the float32 entries; asinf/acosf modelled as correctly rounded.

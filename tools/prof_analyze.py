@@ -30,13 +30,20 @@ raw2 = raw[8 * B:16 * B].reshape(B, 8)
 print("setup phases us (means): region %.1f sort %.1f fill %.1f (marking %.1f, numbering done at %.1f)" % (
     (raw2[:, 6] >> 32).mean() * 0.01, (raw2[:, 6] & 0xFFFFFFFF).mean() * 0.01,
     (raw2[:, 7] >> 32).mean() * 0.01, ((raw2[:, 7] >> 16) & 0xFFFF).mean() * 0.01, (raw2[:, 7] & 0xFFFF).mean() * 0.01))
-names = ["init_state", "region", "sort:histogram", "sort:scan", "sort:scatter", "sort:rank+copy", "publish", "fill:occupancy", "fill:dilate", "fill:number", "fill:records"]
-print("extra stamps 11..15 (absolute us since the scan was taken):", m_extra if (m_extra := stamps.mean(0)[11:16].round(1).tolist()) else "")
+# round 5: the window's plan (7-9) runs inside the ordering, behind the offsets (3); 13 = record lines asked for; 4 = places handed
+# out (the waves' turns) + entries written; 11 = order checked; 12 = (repaired) ; 5 = staged + copied out; 6 = published;
+# 14 = record loads issued; 15 = slot table written; 10 = records in LDS
+order = [(0, "scan loaded, optimiser start"), (1, "region"), (2, "histogram"), (3, "bitmap + offsets"),
+         (4, "places (waves in turn) + entries"), (11, "order checked"), (5, "image of the ordered copy in LDS"),
+         (7, "plan: occupancy"), (8, "plan: dilate"), (9, "plan: number"), (6, "copy-out issued, geometry stored (published)"),
+         (14, "fetch: slot table + cells"), (15, "fetch: loads issued"), (10, "fetch: records in LDS")]
 m = stamps.mean(0)
-print("setup stamps us (mean, cumulative -> delta):")
+print("setup stamps us (mean, in program order: cumulative -> delta):")
 prev = 0.0
-for k, nm in enumerate(names):
-    print("  %-16s %6.1f  (+%.1f)" % (nm, m[k], m[k] - prev)); prev = m[k]
+for k, nm in order:
+    if m[k] == 0:
+        continue
+    print("  %-34s %6.1f  (+%.1f)" % (nm, m[k], m[k] - prev)); prev = m[k]
 
 # ---- timelines of the shared passes (absolute 100 MHz ticks): opened, own units done, collected, h, (seen, done) x 6
 tl = raw[32 * B:].reshape(B, PASSES, 16).astype(np.int64)
