@@ -355,13 +355,28 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
 // and fitness_far_kernel finishes them, 64 queries of ONE kind per wave.  With phase 3 inline a wave walks the rings of its
 // farthest lane while the others wait: on configs[4]'s seeds the longest lane of a wave needs 31 rounds of dependent loads,
 // the average lane 8, and less than half the lanes need the phase at all.
+// XCD-aware numbering of the fitness kernels' workgroups (round 5).  The dispatcher deals consecutive workgroups out to the
+// eight XCDs in turn, each with an L2 of its own; a (gx, B) grid with the match's blocks along x therefore spread every match
+// over all eight L2s: its ordered copy, its ~300 KB of buckets and their offsets were pulled into each of them.  Now the grid
+// is one-dimensional and workgroup w works for XCD w & 7 on that XCD's (w >> 3)-th item, items numbered match-major: all gx
+// blocks of a match on ONE XCD -- the XCD of the workgroup that owned the match in the match kernel (b & 7) and wrote its
+// ordered copy through that L2 -- one match after the other.
+__device__ __forceinline__ bool fit_block_of(int gx, int B, int &b, int &x) {
+  const unsigned w = blockIdx.x, xcd = w & 7u, seq = w >> 3;
+  b = (int)((seq / (unsigned)gx) * 8u + xcd);
+  x = (int)(seq % (unsigned)gx);
+  return b < B;
+}
+
 template <bool SSE, bool DEFER>
 __global__ void __launch_bounds__(256, NDT_FIT_OCC)
 fitness_points_kernel(MapView M, const float *__restrict__ scans, const unsigned long long *__restrict__ offsets, int B,
                       int shared_scan, const float2 *__restrict__ sorted, const ndt_result *__restrict__ results,
-                      float *__restrict__ fit, unsigned *__restrict__ far_idx, unsigned *__restrict__ far_n) {
+                      float *__restrict__ fit, unsigned *__restrict__ far_idx, unsigned *__restrict__ far_n, int gx) {
   __shared__ RingLds ring[256 / 64];
-  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+  int b, bx;
+  if (!fit_block_of(gx, B, b, bx)) return;
+  {
     const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
     const unsigned long long o1 = shared_scan ? offsets[1] : offsets[b + 1];
     const int n = (int)(o1 - o0);
@@ -372,7 +387,7 @@ fitness_points_kernel(MapView M, const float *__restrict__ scans, const unsigned
     const float2 *pts = use_sorted ? sorted + slot : reinterpret_cast<const float2 *>(scans) + o0;
     float *out = fit + slot;
     // whole waves stay together (the ring-1 phase is a wave's joint work): lanes past the end carry no query
-    for (int i0 = blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 < n; i0 += gridDim.x * blockDim.x) {
+    for (int i0 = bx * (int)blockDim.x + (int)(threadIdx.x & ~63u); i0 < n; i0 += gx * (int)blockDim.x) {
       const int i = i0 + (int)(threadIdx.x & 63u);
       const float2 pt = pts[min(i, n - 1)];
       float qx, qy;
@@ -414,11 +429,13 @@ template <bool SSE>
 __global__ void __launch_bounds__(256, NDT_FAR_OCC)
 fitness_far_kernel(MapView M, const float *__restrict__ scans, const unsigned long long *__restrict__ offsets, int B,
                    int shared_scan, const float2 *__restrict__ sorted, const ndt_result *__restrict__ results,
-                   float *__restrict__ fit, const unsigned *__restrict__ far_idx, const unsigned *__restrict__ far_n) {
+                   float *__restrict__ fit, const unsigned *__restrict__ far_idx, const unsigned *__restrict__ far_n, int gx) {
   __shared__ FarLds far_lds;
-  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+  int b, bx;
+  if (!fit_block_of(gx, B, b, bx)) return;
+  {
     const unsigned na = far_n[2 * (size_t)b], nb = far_n[2 * (size_t)b + 1];
-    if (na + nb == 0u) continue;
+    if (na + nb == 0u) return;
     const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
     const unsigned long long o1 = shared_scan ? offsets[1] : offsets[b + 1];
     const int n = (int)(o1 - o0);
@@ -431,7 +448,7 @@ fitness_far_kernel(MapView M, const float *__restrict__ scans, const unsigned lo
     const unsigned *list = far_idx + slot;
     // whole waves of one kind: the front list rounded up to waves, then the back list
     const unsigned wa = (na + 63u) & ~63u, total = wa + nb;
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    for (unsigned e = (unsigned)bx * blockDim.x + threadIdx.x; e < total; e += (unsigned)gx * blockDim.x) {
       unsigned i;
       if (e < wa) { if (e >= na) continue; i = list[e]; }
       else i = list[(unsigned)(n - 1) - (e - wa)];

@@ -311,20 +311,21 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   {
     const size_t avg = shared_scan ? total_points : (total_points + (size_t)B - 1) / (size_t)B;
     const unsigned gx = (unsigned)std::min<size_t>(64, std::max<size_t>(1, (avg + 255) / 256));
-    const dim3 grid(gx, (unsigned)std::min(B, 65535));
+    // one-dimensional, XCD-aware: workgroup w -> (match, block of the match) in fit_block_of (ndt_fitness.hip.h)
+    const dim3 grid(gx * (unsigned)(((size_t)B + 7) / 8 * 8));
     if (shared_scan) {
       // hypothesis scoring: most seeds end far from the map -- the far phase of the search as a pass of its own over the
       // queries that need it (ndt_fitness.hip.h)
       const size_t cnt_bytes = far_cnt_bytes;
       unsigned *far_n = (unsigned *)ctx->d_far, *far_idx = (unsigned *)((unsigned char *)ctx->d_far + cnt_bytes);
       { hipError_t e = hipMemsetAsync(far_n, 0, cnt_bytes, st); if (e != hipSuccess) return entered(fail(ctx, NDT_E_HIP, std::string("launch_align: hipMemsetAsync: ") + hipGetErrorString(e))); }
-      if (sse) fitness_points_kernel<true, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n);
-      else     fitness_points_kernel<false, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n);
-      if (sse) fitness_far_kernel<true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n);
-      else     fitness_far_kernel<false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n);
+      if (sse) fitness_points_kernel<true, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
+      else     fitness_points_kernel<false, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
+      if (sse) fitness_far_kernel<true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
+      else     fitness_far_kernel<false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
     } else {
-      if (sse) fitness_points_kernel<true, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr);
-      else     fitness_points_kernel<false, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr);
+      if (sse) fitness_points_kernel<true, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr, (int)gx);
+      else     fitness_points_kernel<false, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr, (int)gx);
     }
     hipExtLaunchKernelGGL(fitness_reduce_kernel, dim3(std::min(B, 4 * ctx->num_cus)), dim3(kFitBlock), 0, st, nullptr, evr[2], 0,
                           offsets, B, shared_scan, (const float *)fit, out, (uint4 *)ws, (unsigned)(zero_bytes / 16));

@@ -106,6 +106,73 @@ if "SQ_INSTS_VALU" in mean:
         valu["wave_time_waiting"] = mean["SQ_WAIT_ANY"] / mean["SQ_WAVE_CYCLES"] if "SQ_WAVE_CYCLES" in mean else None
     json.dump(valu, open(os.path.join(P, pre + "valu.json"), "w"), indent=1)
 
+# ---- round 5: the other kernels that carry a `frac` in the bench line, profiled on their own (tools/gpu_profile.sh parts i-iii)
+def mean_by_kernel(path, counter):
+    """mean per dispatch of one counter for every kernel of a rocprofv3 --pmc run"""
+    acc = collections.defaultdict(list)
+    if not os.path.exists(path):
+        return {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            acc[kname(r["Kernel_Name"])].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in acc.items()}
+
+
+def traffic_json(name, kernels_note, fetch, write, per_what, src):
+    kb_f = sum(fetch.values()); kb_w = sum(write.values())
+    json.dump({"kernels": kernels_note, "per": per_what, "source": src,
+               "fetch_size_kb": kb_f, "write_size_kb": kb_w, "bytes_per_launch": (2.0 * kb_f + kb_w) * 1024.0,
+               "by_kernel_kb": {k: {"fetch": fetch.get(k, 0.0), "write": write.get(k, 0.0)} for k in sorted(set(fetch) | set(write))},
+               "note": "sum over the chain's kernels of their mean per dispatch; (2 x FETCH_SIZE + WRITE_SIZE) x 1024, calib_fetch as in "
+                       "%straffic.json" % pre}, open(os.path.join(P, pre + name), "w"), indent=1)
+
+
+# fitness kernels: their counters come with the bench's own --pmc passes (a counter pass serialises the kernels: per-dispatch
+# values are each kernel's own), their time ALONE from the synchronous loop (alone_stats)
+ff = {k: v for k, v in mean_by_kernel(os.path.join(G, "pmc_fetch", "run_counter_collection.csv"), "FETCH_SIZE").items() if k.startswith("fitness_")}
+fw = {k: v for k, v in mean_by_kernel(os.path.join(G, "pmc_write", "run_counter_collection.csv"), "WRITE_SIZE").items() if k.startswith("fitness_")}
+if ff:
+    traffic_json("fitness_traffic.json", "fitness_points_kernel + fitness_reduce_kernel", ff, fw, "launch of 256 matches",
+                 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the bench (profiles/%spmc_fetch.csv, %spmc_write.csv)" % (pre, pre))
+for part, out in (("alone_stats", "alone_kernel_stats.csv"), ("build_stats", "build_kernel_stats.csv"), ("c5_stats", "c5_kernel_stats.csv")):
+    src = os.path.join(G, part, "run_kernel_stats.csv")
+    if os.path.exists(src):
+        shutil.copy(src, os.path.join(P, pre + out))
+bf = {k: v for k, v in mean_by_kernel(os.path.join(G, "build_fetch", "run_counter_collection.csv"), "FETCH_SIZE").items() if k.startswith(("map_", "scan_", "fill_"))}
+bw = {k: v for k, v in mean_by_kernel(os.path.join(G, "build_write", "run_counter_collection.csv"), "WRITE_SIZE").items() if k.startswith(("map_", "scan_", "fill_"))}
+if bf:
+    traffic_json("build_traffic.json", "the chain of ndt_map_build_dev", bf, bw, "build of the 1M-point map",
+                 "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes -- python3 tools/prof_build.py 10 C3 (a build-only loop)")
+for n in ("c5_bench.log", "c5_stats.log"):
+    if os.path.exists(os.path.join(G, n)):
+        open(os.path.join(P, pre + n.replace(".log", ".json")), "w").write(json.dumps(line_of(os.path.join(G, n))) + "\n")
+c5f = {k: v for k, v in mean_by_kernel(os.path.join(G, "c5_fetch", "run_counter_collection.csv"), "FETCH_SIZE").items() if k.startswith("fitness_")}
+c5w = {k: v for k, v in mean_by_kernel(os.path.join(G, "c5_write", "run_counter_collection.csv"), "WRITE_SIZE").items() if k.startswith("fitness_")}
+if c5f:
+    traffic_json("c5_fitness_traffic.json", "fitness_points_kernel + fitness_far_kernel + fitness_reduce_kernel (configs[4])", c5f, c5w,
+                 "launch of 512 seeds", "rocprofv3 --pmc passes of `bench.py --config C5 --no-cpu-baseline --no-single-scan --steps 6`")
+c5v = os.path.join(G, "c5_valu", "run_counter_collection.csv")
+if os.path.exists(c5v):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(c5v)):
+        per[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    outv = {}
+    for k, c in per.items():
+        if not (k.startswith("fitness_") or k.startswith("ndt_align")):
+            continue
+        mk = {n: sum(v) / len(v) for n, v in c.items()}
+        outv[k] = {"counters": mk, "valu_lane_util": mk["SQ_THREAD_CYCLES_VALU"] / (mk["SQ_ACTIVE_INST_VALU"] * 64.0) if mk.get("SQ_ACTIVE_INST_VALU") else None,
+                   "lanes_of_64": mk["SQ_THREAD_CYCLES_VALU"] / mk["SQ_ACTIVE_INST_VALU"] if mk.get("SQ_ACTIVE_INST_VALU") else None}
+    json.dump({"workload": "bench.py --config C5 (512 seeds x one 10k-pt scan vs the 5M-point map)", "kernels": outv},
+              open(os.path.join(P, pre + "c5_valu.json"), "w"), indent=1)
+vm = os.path.join(G, "pmc_vmem", "run_counter_collection.csv")
+if os.path.exists(vm):
+    per = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(vm)):
+        per[kname(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    json.dump({k: {n: sum(v) / len(v) for n, v in c.items()} for k, c in per.items() if k.startswith(("ndt_align", "fitness_"))},
+              open(os.path.join(P, pre + "vmem_insts.json"), "w"), indent=1)
+
 k = stats["ndt_align_kernel"]
 print("match kernel: calls %s avg %.1f us | fetch %.0f MB write %.0f MB" % (
     k["Calls"], float(k["AverageNs"]) / 1e3, mean["FETCH_SIZE"] * 1024 / 1e6, mean["WRITE_SIZE"] * 1024 / 1e6))
