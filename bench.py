@@ -118,6 +118,8 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=1, choices=[1, 2, 3, 4], help="match launches in flight (k: k contexts / streams in turn, k + 1 map buffers)")
     ap.add_argument("--workgroups", type=int, default=0, help="workgroups per match launch (0 = one per CU); fewer leave CUs to the map build's stream")
     ap.add_argument("--max-helpers", type=int, default=-1, help="helper workgroups per unfinished scan (default -1: the library chooses, 2 for whole-GPU batches and 8 below); fewer free CUs earlier for whatever is queued behind the launch")
+    ap.add_argument("--prepare", choices=["off", "build-stream", "own-stream"], default="off",
+                    help="prepare batch i ahead of its launch (ndt_align_batch_prepare_dev: optimiser start, window geometry and voxel order as a kernel of its own): behind the step's rebuild on the build stream, or on a stream of its own queued first.  Off by default: the match kernel is 18 us shorter with it (roofline.frac 0.30 -> 0.32) but the step is not -- the order kernel's 1024-thread workgroups need whole CUs and only get them when the fitness kernels of the step before are through (LOG R5.2)")
     ap.add_argument("--time-builds", action="store_true", help="extra events around the map build and around the whole launch inside the step loop (launch_interval_ms, map_build_in_step_ms)")
     ap.add_argument("--no-scatter", action="store_true", help="N > 1: every rank generates its own shard instead of receiving it from rank 0")
     ap.add_argument("--map-from-rank0", action="store_true", help="N > 1: only rank 0 generates the target cloud, the others build their map from shard.broadcast_map's copy (by default every rank generates it AND the broadcast is timed and checked against it: comm.broadcast_map_ms)")
@@ -358,6 +360,7 @@ class Pipeline:
         self.gathered = [None] * self.nbuf
         torch.cuda.synchronize()
         self.bstream = torch.cuda.Stream(device=dev, priority=-1)     # map builds: small kernels, first in line for freed CUs
+        self.pstream = torch.cuda.Stream(device=dev, priority=-1) if args.prepare == "own-stream" else None   # batches prepared ahead (ndt_order_kernel)
         self.bctx = capi.Context(env.local_rank)
         self.bctx.set_stream(self.bstream.cuda_stream)
         self.gmaps = [capi.Map(self.bctx, params=self.prm, dev_ptr=self.d_map.data_ptr(), n=len(I.map_xy), stride=8)
@@ -446,6 +449,15 @@ class Pipeline:
     def step(self, i):
         args = self.args
         gm = self.gmaps[i % self.nbuf]
+        def prepare(stream):
+            # the part of step i's matches that needs nothing but the scans, their guesses and the grid's geometry -- optimiser
+            # start, window geometry, voxel order -- as a kernel of its own (ndt_align_batch_prepare_dev; the launch below finds
+            # the prepared batch)
+            I = self.I
+            gm.prepare_batch_dev(I.d_scans.data_ptr(), I.d_off.data_ptr(), I.B, I.total_points, I.d_init.data_ptr(),
+                                 shared_scan=I.c5, stream=stream.cuda_stream, ctx=self.mctx[i % args.inflight])
+        if args.prepare == "own-stream":
+            prepare(self.pstream)
         # a2: rebuild the voxel grid of this step in place, as soon as the matches of step i - nbuf (the last
         # readers of this grid) are done
         if i >= self.nbuf:
@@ -458,6 +470,8 @@ class Pipeline:
         self.settle_build()
         gm.rebuild_begin(self.cloud_of(i).data_ptr(), len(self.I.map_xy), 8)
         self.open_build.append((gm, i))
+        if args.prepare == "build-stream":
+            prepare(self.bstream)
         if args.time_builds:
             self.ev_m[2 * i + 1].record(self.bstream)
         self.launch(i)
@@ -503,6 +517,7 @@ def kernel_figures(pipe, env, args):
         later = len([j for j in range(i + 1, nst) if j % k == i % k])
         if later < 64:
             per_launch.append(pipe.mctx[i % k].kernel_timing(later))
+    F.order_ms = float(max(c.prepare_timing() for c in pipe.mctx))
     F.match_ms = float(np.mean([t[0] for t in per_launch]))
     F.fit_ms = float(np.mean([t[1] for t in per_launch]))
     # step-to-step intervals inside the timed region (start of a launch's match kernel to the start of the next one's),
@@ -919,6 +934,7 @@ def headline(env, args, I, pipe, F, elapsed, rebuilt_timed, legs):
                                "`reference_faithful` rebuilds synchronously); %d match launch(es) in flight; parameter preset PCL 1.10" % args.inflight,
                    "matches_per_gpu": B, "scans_per_gpu": B if not c5 else 1, "scan_points": n_scan, "map_points": cfg["n_map"],
                    "resolution": cfg["resolution"], "inflight": args.inflight, "workgroups": args.workgroups, "max_helpers": args.max_helpers,
+                   "prepared_ahead": args.prepare,
                    "parallelism": ("seed-shards x%d, scan broadcast, arg-max of scores" % world) if c5 else
                                   ("scan-shards x%d, %s, gather of results" % (world, "every rank generates its shard" if (args.no_scatter or world == 1) else "scatter from rank 0"))},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -932,6 +948,10 @@ def headline(env, args, I, pipe, F, elapsed, rebuilt_timed, legs):
                              "algorithmic bytes (DESIGN.md 4.2).  The fitness score (N x 16 B per match) is a kernel of its "
                              "own, listed under `fitness`",
                      "kernel": "ndt_align_kernel", "kernel_ms": F.match_ms,
+                     "order_kernel": {"kernel": "ndt_order_kernel", "ms": F.order_ms, "prepared_ahead": args.prepare,
+                                      "note": "optimiser start + window geometry + voxel order of the step's scans as a kernel of its own on the build "
+                                              "stream, behind the map's rebuild (ndt_align_batch_prepare_dev): it runs while the previous step's "
+                                              "matches run out; with --no-prepare the owners do the same work inside ndt_align_kernel (+ ~20 us per scan)"},
                      "launch_interval_ms": float(np.mean(F.kern_ms)) if F.kern_ms else None,
                      "fitness": {"kernels": "fitness_points_kernel + fitness_far_kernel + fitness_reduce_kernel" if c5 else "fitness_points_kernel + fitness_reduce_kernel", "ms": F.fit_ms,
                                  "algorithmic_bytes_per_launch": fit_bytes,

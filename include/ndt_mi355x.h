@@ -209,6 +209,25 @@ int ndt_align_batch(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_host
 int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_dev,
                         const uint64_t *offsets_dev, int B, size_t total_points, int shared_scan,
                         const double *inits_dev, ndt_result *out_dev, void *stream);
+/* Optional first half of ndt_align_batch_dev for a caller with a STREAM of batches: what an alignment needs before its first
+ * derivative pass -- the optimiser's start from the initial guess (src/PoseEstimator.cpp:22-24 and computeTransformation's
+ * prologue), the window of the voxel grid the scan can reach, the scan's points in voxel order -- depends
+ * on the scan, its guess and the grid of `map` only.  This call queues that work for the whole batch on `stream` (NULL: the
+ * context's) as a kernel of its own and returns; a later ndt_align_batch_dev(ctx, map, <the same scans, offsets, B,
+ * total_points, shared_scan, inits>, ...) finds the prepared batch, orders its stream behind it and starts every scan at the
+ * staging of its window.  Of `map` it uses the voxel grid's geometry as it is at the time of the call and reads nothing on the
+ * device, so it needs no ordering against the map's builds: put it where the GPU has room while the previous batch's matches
+ * run out (bench.py: on a stream of its own, queued before the step's rebuild).  Rules: the arrays must not change between the
+ * two calls; if the map is rebuilt in between and its grid comes out different (another cloud; a two-phase rebuild whose
+ * ndt_map_rebuild_end returns NDT_REBUILT) the prepared batch is simply not used; one prepared batch serves one
+ * launch; two batches may be prepared ahead per context.  Results are byte-identical with and without it (the same device
+ * routines run, earlier).  One scan at a time (src/ScanMatcher.cpp:40,45 as the reference calls it) gains nothing from it. */
+int ndt_align_batch_prepare_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans_xy_dev,
+                                const uint64_t *offsets_dev, int B, size_t total_points, int shared_scan,
+                                const double *inits_dev, void *stream);
+/* Duration (ms) of the kernel ndt_align_batch_prepare_dev queued for the batches the context's launches used; 0 when
+ * none was used.  Blocks until that kernel has run. */
+int ndt_prepare_timing(ndt_ctx *ctx, float *order_ms);
 
 /* Many matches over several GPUs from ONE process (north_star: "batch across the 8 GPUs of one node"; SURVEY.md 8b's
  * indicative multi-device context): `ctxs[r]` / `maps[r]` are a context of device r and a map built there from the same

@@ -57,7 +57,7 @@ EXPORTS = [
     "ndt_default_params", "ndt_params_pcl110", "ndt_params_pcl18", "ndt_params_pcl_new", "ndt_ctx_create", "ndt_ctx_destroy", "ndt_last_error", "ndt_ctx_stream",
     "ndt_ctx_set_stream", "ndt_ctx_set_option", "ndt_ctx_wait_launch",
     "ndt_map_build", "ndt_map_build_dev", "ndt_map_rebuild_begin", "ndt_map_rebuild_end", "ndt_map_destroy", "ndt_map_info_get", "ndt_map_export",
-    "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_trace", "ndt_eval_at",
+    "ndt_align", "ndt_align_batch", "ndt_align_batch_dev", "ndt_align_batch_prepare_dev", "ndt_prepare_timing", "ndt_align_batch_trace", "ndt_eval_at",
     "ndt_fitness_at", "ndt_last_timing", "ndt_kernel_timing", "ndt_launch_interval", "ndt_align_batch_sharded", "ndt_prefilter", "ndt_prefilter_batch_dev",
     "ndt_fuse_default_params", "ndt_predict_batch_dev", "ndt_fuse_batch_dev",
     "ndt_remove_neighbors", "ndt_remove_neighbors_dev",
@@ -97,6 +97,8 @@ def lib():
     L.ndt_align.argtypes = [vp, vp, vp, sz, sz, vp, vp]
     L.ndt_align_batch.argtypes = [vp, vp, vp, vp, i, i, vp, vp]
     L.ndt_align_batch_dev.argtypes = [vp, vp, vp, vp, i, sz, i, vp, vp, vp]
+    L.ndt_align_batch_prepare_dev.argtypes = [vp, vp, vp, vp, i, sz, i, vp, vp]
+    L.ndt_prepare_timing.argtypes = [vp, C.POINTER(C.c_float)]
     L.ndt_align_batch_trace.argtypes = [vp, vp, vp, vp, i, i, vp, vp, vp, i, vp]
     L.ndt_eval_at.argtypes = [vp, vp, vp, sz, sz, vp, vp, vp, vp, vp]
     L.ndt_fitness_at.argtypes = [vp, vp, vp, sz, sz, C.c_float, C.c_float, C.c_float, C.c_float, vp]
@@ -298,6 +300,12 @@ class Context:
         self.check(lib().ndt_kernel_timing(self.h, back, C.byref(a), C.byref(b)), "ndt_kernel_timing")
         return a.value, b.value
 
+    def prepare_timing(self):
+        """ms of the kernel of the prepared batch(es) this context's launches used (0.0: none)."""
+        a = C.c_float()
+        self.check(lib().ndt_prepare_timing(self.h, C.byref(a)), "ndt_prepare_timing")
+        return a.value
+
     def launch_interval(self, back=0):
         """ms from the start of the match kernel of launch back + 1 to the start of launch back (both among the last 64)."""
         a = C.c_float()
@@ -396,6 +404,13 @@ class Map:
         cx = ctx if ctx is not None else self.ctx
         cx.check(lib().ndt_align_batch_dev(cx.h, self.h, scans_ptr, offsets_ptr, B, total_points,
                                            int(shared_scan), inits_ptr, out_ptr, stream), "ndt_align_batch_dev")
+
+    def prepare_batch_dev(self, scans_ptr, offsets_ptr, B, total_points, inits_ptr, shared_scan=False, stream=None, ctx=None):
+        """ndt_align_batch_prepare_dev: the optimiser's start, the window geometry and the voxel order of every scan of a batch,
+        queued on `stream` ahead of the align_batch_dev call with the same arguments (and the same `ctx`); asynchronous."""
+        cx = ctx if ctx is not None else self.ctx
+        cx.check(lib().ndt_align_batch_prepare_dev(cx.h, self.h, scans_ptr, offsets_ptr, B, total_points,
+                                                   int(shared_scan), inits_ptr, stream), "ndt_align_batch_prepare_dev")
 
     def eval_at(self, scan, p):
         scan = _f32c(scan)

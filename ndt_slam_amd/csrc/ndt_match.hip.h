@@ -1043,6 +1043,62 @@ __device__ __forceinline__ u64 wave_bcast64(u64 v) {   // lane 0's value to the 
   return ((u64)hi << 32) | lo;
 }
 
+// ------------------------------------------------------------------------------------------
+// A batch prepared ahead (round 5; ndt_align_batch_prepare_dev).  What an owner does with a scan before it can stage the
+// window -- the optimiser's start, the window geometry, the spatial order, the marked-cell bitmap -- depends on the scan,
+// its initial guess and the map's grid only, not on anything the matches compute: a caller with a stream of batches can have
+// it done for batch i + 1 while the matches of batch i run out (the CUs their workgroups leave are idle otherwise).
+// ndt_order_kernel runs the owner's own routines (order_scan_regs, copy_out_ordered) and leaves per scan one PrepRec, the
+// bitmap and the ordered copy; an owner that finds a record for its scan starts at the window's staging: 33 -> ~10 us of
+// set-up inside the match kernel.  Same routines, same data: the records of a prepared batch are byte-identical.
+// ------------------------------------------------------------------------------------------
+struct alignas(16) PrepRec {
+  int region[6];                 // Region of the scan's window
+  int clipped, ok;               // ok: 1 = this scan has been prepared (0: the owner does it itself, e.g. a scan beyond kSortRegs points)
+  AlignState S;                  // the optimiser's start (init_state)
+};
+constexpr int kPrepWords = (int)(sizeof(PrepRec) / 4);
+static_assert(sizeof(PrepRec) % 16 == 0 && kPrepWords <= kBlock, "PrepRec is copied word by word by one workgroup");
+
+template <bool SSE>
+__global__ void __launch_bounds__(kBlock)
+ndt_order_kernel(MapView M, OptParams P, const float *__restrict__ scans, const unsigned long long *__restrict__ offsets,
+                 int B, int shared_scan, const double *__restrict__ inits, float2 *__restrict__ sorted,
+                 PrepRec *__restrict__ prep, unsigned *__restrict__ prep_map /* [B][kRegionCells / 32] */) {
+  Lds &L = g_L;
+  uint4 *const pool = g_pool;
+  if (threadIdx.x == 64) { L.M = M; L.P = P; }
+  __syncthreads();
+  for (int b = (int)blockIdx.x; b < B; b += (int)gridDim.x) {
+    const u64 o0 = shared_scan ? offsets[0] : offsets[b];
+    const u64 o1 = shared_scan ? offsets[1] : offsets[b + 1];
+    const int n = (int)(o1 - o0);
+    PrepRec *R = prep + b;
+    if (!(n > 0 && n <= kSortRegs)) {                          // (uniform) left to the owner's streaming routines
+      if (threadIdx.x == 0) R->ok = 0;
+      continue;
+    }
+    const float2 *scan = reinterpret_cast<const float2 *>(scans) + o0;
+    float2 *sp = shared_scan ? sorted + (size_t)b * (size_t)n : sorted + o0;
+    order_scan_regs<SSE, kSortRegs / kBlock>(L.M, L.P, inits + 3 * (size_t)b, scan, n, L, pool, sp);
+    copy_out_ordered(pool, sp, n);
+    if (threadIdx.x == 0) {
+      const Region r = L.RG;
+      R->region[0] = r.x0; R->region[1] = r.y0; R->region[2] = r.rw; R->region[3] = r.rh; R->region[4] = r.cap; R->region[5] = 0;
+      R->clipped = L.clipped; R->ok = 1;
+    }
+    {
+      const u32 *src = reinterpret_cast<const u32 *>(&L.S);
+      u32 *dst = reinterpret_cast<u32 *>(&R->S);
+      if (threadIdx.x < sizeof(AlignState) / 4) dst[threadIdx.x] = src[threadIdx.x];
+      const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
+      unsigned *gm = prep_map + (size_t)b * (kRegionCells / 32);
+      for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) gm[i] = wmap[i];
+    }
+    __syncthreads();
+  }
+}
+
 template <bool SSE, bool INCL>
 __global__ void __launch_bounds__(kBlock)
 ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
@@ -1052,7 +1108,9 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
                  float2 *__restrict__ sorted /* scratch, same offsets as scans; may be null */,
                  unsigned char *__restrict__ ws /* WsHeader, ScanCtl[B], unit totals[B][kUnits][24], marked-cell bitmaps[B][kRegionCells/32] */,
                  int allow_helpers /* 0: none; else max helper workgroups per scan */,
-                 unsigned long long *__restrict__ prof /* diagnostic: 8 words per scan */) {
+                 unsigned long long *__restrict__ prof /* diagnostic: 8 words per scan */,
+                 const PrepRec *__restrict__ prep /* batch prepared ahead (ndt_order_kernel), or null */,
+                 const unsigned *__restrict__ prep_map) {
   Lds &L = g_L;
   uint4 *const pool = g_pool;
   WsHeader *hdr = reinterpret_cast<WsHeader *>(ws);
@@ -1096,6 +1154,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     // scans that fit the register-resident set-up (order_scan_regs) get their optimiser state set up in there, under the
     // latency of the scan's first touch
     const bool reg_path = n > 0 && sorted != nullptr && n <= kSortRegs;
+    const bool prepared = reg_path && prep != nullptr && prep[b].ok != 0;        // (uniform: one word per scan)
     if (threadIdx.x == 0) {
       u32 expect = 0u;
       const bool won = !allow_helpers || b >= (int)gridDim.x || b == preclaimed ||
@@ -1125,7 +1184,22 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       // scratch copy: at the scan's own offsets, or (every match uses scan 0) one slot per match
       float2 *sp = sorted ? (shared_scan ? sorted + (size_t)b * (size_t)n : sorted + o0) : nullptr;
       u64 q1 = 0;
-      if (reg_path) {
+      if (prepared) {
+        // ordered ahead of the launch: the optimiser's start, the geometry and the bitmap come from the record, the copy is in place
+        const PrepRec *R = prep + b;
+        if (threadIdx.x < sizeof(AlignState) / 4)
+          reinterpret_cast<u32 *>(&L.S)[threadIdx.x] = reinterpret_cast<const u32 *>(&R->S)[threadIdx.x];
+        if (threadIdx.x == 64) {
+          Region r; r.x0 = R->region[0]; r.y0 = R->region[1]; r.rw = R->region[2]; r.rh = R->region[3]; r.cap = R->region[4]; r.nspill = 0;
+          L.RG = r; L.clipped = R->clipped;
+        }
+        unsigned *wmap = reinterpret_cast<unsigned *>(L.wpart);
+        const unsigned *gm = prep_map + (size_t)b * (kRegionCells / 32);
+        for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) wmap[i] = gm[i];
+        pts = sp;
+        __syncthreads();
+        NDT_STAMP(stamps, t0s, 0);
+      } else if (reg_path) {
         order_scan_regs<SSE, kSortRegs / kBlock>(L.M, L.P, inits + 3 * (size_t)b, scan, n, L, pool, sp, stamps, t0s); pts = sp;
       } else {
         compute_region<SSE>(L.M, L.S.T, scan, n, L);
@@ -1139,7 +1213,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       // Which voxels get a record (control block only; its loads of the map's occupancy words are in front of the copy's
       // stores: a wait for a load is a wait for every store issued before it), then the ordered copy on its way to memory.
       fill_window_plan(L.M, L, stamps, t0s);
-      if (reg_path) copy_out_ordered(pool, sp, n);
+      if (reg_path && !prepared) copy_out_ordered(pool, sp, n);
       if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
         const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
         unsigned *gw = wantmap + (size_t)b * (kRegionCells / 32);
@@ -1358,8 +1432,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       R_.ref_evals = S.ref_evals + 1;       // + the getHessian pass (src/PoseEstimator.cpp:56)
       R_.converged = S.converged;
       R_.status = aborted ? NDT_E_HIP : (n > 0 ? NDT_OK : NDT_E_ARG);
-      R_.flags = (L.RG.nspill > 0 ? NDT_FLAG_WINDOW_SPILL : 0) | (L.clipped ? NDT_FLAG_REGION_CLIPPED : 0) |
-                 ((n > 0 && pts == scan) ? NDT_FLAG_UNSORTED : 0);
+      R_.flags = n > 0 ? ((L.RG.nspill > 0 ? NDT_FLAG_WINDOW_SPILL : 0) | (L.clipped ? NDT_FLAG_REGION_CLIPPED : 0) |
+                          (pts == scan ? NDT_FLAG_UNSORTED : 0)) : 0;      // (an empty scan has no window: nothing left over from the scan before it)
       R_.kbar = (S.evals > 0 && n > 0) ? S.pairs / ((double)S.evals * (double)n) : 0.0;
       results[b] = R_;
       if (allow_helpers) {

@@ -90,6 +90,23 @@ struct ndt_ctx {
   int helpers = -1;                                    // NDT_OPT_MAX_HELPERS: helper workgroups per scan (0: no work sharing; -1: by the size of the launch)
   int workgroups = 0;                                  // NDT_OPT_WORKGROUPS: workgroups of a match launch (0: one per CU)
   int inject_fault = 0;                                // NDT_OPT_INJECT_FAULT (tests): the k-th next match launch fails behind its first kernel
+  // Batches prepared ahead (ndt_align_batch_prepare_dev): two sets of buffers in turn -- ordered copies, records, bitmaps -- that
+  // belong to no scratch bracket: set s is written by the prepare call for batch i + 1 while the launch of batch i, which reads
+  // the other set, is still running; the prepare call orders itself behind the last launch that read ITS set.
+  struct PrepSet {
+    void *sorted = nullptr; size_t sorted_cap = 0;
+    void *recs = nullptr; size_t recs_cap = 0;
+    void *maps = nullptr; size_t maps_cap = 0;
+    hipEvent_t ev0 = nullptr, ready = nullptr;         // around ndt_order_kernel (on its dispatch)
+    bool valid = false, timed = false;
+    // what the set was prepared for
+    const void *scans = nullptr, *offsets = nullptr, *inits = nullptr, *map = nullptr;
+    int B = 0, shared_scan = 0; size_t total_points = 0;
+    int min_bx = 0, min_by = 0, div_x = 0, div_y = 0; float inv_leaf = 0.f;
+    long long reader = -1;                             // number of the last launch of this context that read the set (-1: none)
+  } prep[2];
+  int prep_last = 1;                                   // set of the most recent prepare call
+  float order_ms = 0.f;                                // ndt_order_kernel of the prepared batch the last launch used
   // The grow-only scratch above belongs to the context, not to a stream: a call on another stream than the
   // previous one first waits for the previous user (ev_scratch).
   hipEvent_t ev_scratch = nullptr; hipStream_t scratch_stream = nullptr; bool scratch_used = false, scratch_recorded = false;
@@ -245,7 +262,8 @@ int grid_for(size_t n, int block, int cap = 2048) {
 
 int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *scans,
                  const unsigned long long *offsets, int B, int shared_scan, size_t total_points, const double *inits,
-                 ndt_result *out, double *trace, int trace_cap, int *trace_rows, unsigned long long *prof) {
+                 ndt_result *out, double *trace, int trace_cap, int *trace_rows, unsigned long long *prof,
+                 ndt_ctx::PrepSet *pset = nullptr) {
   const bool sse = map->prm.transform_sse != 0, incl = map->prm.radius_inclusive != 0;
   const MapView &V = map->view;
   const OptParams O = opt_of(map->prm);
@@ -262,7 +280,9 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   const size_t slots = (shared_scan ? (size_t)B : (size_t)1) * total_points;
   if ((rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, slots * sizeof(float2) + 16))) return rc;
   if ((rc = ensure(ctx, &ctx->d_fit, &ctx->d_fit_cap, slots * sizeof(float) + 16))) return rc;
-  float2 *sorted = (float2 *)ctx->d_sorted;
+  float2 *sorted = pset ? (float2 *)pset->sorted : (float2 *)ctx->d_sorted;      // (a prepared batch: its ordered copies are in its own set)
+  const PrepRec *prep = pset ? (const PrepRec *)pset->recs : nullptr;
+  const unsigned *prep_map = pset ? (const unsigned *)pset->maps : nullptr;
   float *fit = (float *)ctx->d_fit;
   // (every allocation of the launch in front of its first kernel: nothing below can fail for want of memory once work is queued)
   const size_t far_cnt_bytes = ((size_t)B * 2 * sizeof(unsigned) + 15) & ~(size_t)15;
@@ -284,7 +304,7 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   hipEvent_t *evr = ctx->ev_ring + 3 * (ctx->launches % ndt_ctx::kTimeRing);
 #define NDT_LAUNCH(S_, I_)                                                                                          \
   hipExtLaunchKernelGGL((ndt_align_kernel<S_, I_>), dim3(grid), dim3(kBlock), 0, st, evr[0], evr[1], 0, V, O, scans, \
-                        offsets, B, shared_scan, inits, out, trace, trace_cap, trace_rows, sorted, ws, helpers, prof)
+                        offsets, B, shared_scan, inits, out, trace, trace_cap, trace_rows, sorted, ws, helpers, prof, prep, prep_map)
   if (sse && incl) NDT_LAUNCH(true, true);
   else if (sse)    NDT_LAUNCH(true, false);
   else if (incl)   NDT_LAUNCH(false, true);
@@ -301,6 +321,7 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
       bool found = false;
       for (auto &r : rd) if (r.first == ctx) { r.second = ctx->launches; found = true; }
       if (!found) rd.emplace_back(ctx, ctx->launches);
+      if (pset) pset->reader = (long long)ctx->launches;
       ctx->launches++;
     }
     return code;
@@ -464,6 +485,14 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   if (c->ev_mm) e = hipEventDestroy(c->ev_mm);
   if (c->ev_scratch) e = hipEventDestroy(c->ev_scratch);
   for (hipEvent_t r : c->ev_ring) if (r) e = hipEventDestroy(r);
+  for (ndt_ctx::PrepSet &S : c->prep) {
+    if (S.ready && S.scans) e = hipEventSynchronize(S.ready);      // (its kernel may have been queued on another stream than the context's)
+    if (S.ev0) e = hipEventDestroy(S.ev0);
+    if (S.ready) e = hipEventDestroy(S.ready);
+    if (S.sorted) e = hipFree(S.sorted);
+    if (S.recs) e = hipFree(S.recs);
+    if (S.maps) e = hipFree(S.maps);
+  }
   if (c->h_mm) e = hipHostFree(c->h_mm);
   void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_fit, c->d_far, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
   for (void *b : bufs) if (b) e = hipFree(b);
@@ -865,6 +894,52 @@ int ndt_map_export(const ndt_map *cm, int *cell_idx, float *cent_xy, double *mea
   return NDT_OK;
 }
 
+// A batch prepared ahead of its launch (see PrepRec, ndt_match.hip.h).  Asynchronous, on `stream` (NULL: the context's): the
+// caller of a stream of batches puts it where the GPU has room -- e.g. behind the map's rebuild on the stream that carries the
+// builds -- and issues ndt_align_batch_dev with the SAME arguments later; that call finds the prepared set, makes its stream
+// wait for it and starts every scan at the window's staging.
+int ndt_align_batch_prepare_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, const uint64_t *offsets,
+                                int B, size_t total_points, int shared_scan, const double *inits, void *stream) {
+  if (!ctx) return fail(nullptr, NDT_E_ARG, "null context");
+  if (!map || !scans || !offsets || !inits || B <= 0 || total_points == 0)
+    return fail(ctx, NDT_E_ARG, "ndt_align_batch_prepare_dev: bad arguments");
+  if (map->ctx->device != ctx->device) return fail(ctx, NDT_E_ARG, "ndt_align_batch_prepare_dev: the map was built on another device");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
+  ndt_ctx::PrepSet &S = ctx->prep[ctx->prep_last ^ 1];
+  S.valid = false;
+  const size_t slots = (shared_scan ? (size_t)B : (size_t)1) * total_points;
+  int rc;
+  if ((rc = ensure(ctx, &S.sorted, &S.sorted_cap, slots * sizeof(float2) + 16))) return rc;
+  if ((rc = ensure(ctx, &S.recs, &S.recs_cap, (size_t)B * sizeof(PrepRec)))) return rc;
+  if ((rc = ensure(ctx, &S.maps, &S.maps_cap, (size_t)B * (kRegionCells / 8)))) return rc;
+  if (!S.ready) { HIP_TRY(ctx, hipEventCreate(&S.ev0)); HIP_TRY(ctx, hipEventCreate(&S.ready)); }
+  // Of the map it takes the grid's geometry (by value, now) and reads nothing on the device: no wait for a build that may be
+  // queued or running -- a two-phase rebuild that ends with another grid simply leaves this set unused.  It is ordered behind
+  // the last launch that read this set (its fitness kernels walk the set's ordered copies).
+  if (S.reader >= 0 && (unsigned long long)S.reader < ctx->launches) {
+    const bool wrapped = ctx->launches - 1 - (unsigned long long)S.reader >= (unsigned long long)ndt_ctx::kTimeRing;
+    const unsigned long long which = wrapped ? ctx->launches - 1 : (unsigned long long)S.reader;
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_ring[3 * (which % ndt_ctx::kTimeRing) + 2], 0));
+  }
+  const MapView &V = map->view;
+  const OptParams O = opt_of(map->prm);
+  const int ncu = ctx->workgroups > 0 ? ctx->workgroups : ctx->num_cus;
+  const int grid = B < ncu ? B : ncu;
+  if (map->prm.transform_sse)
+    hipExtLaunchKernelGGL((ndt_order_kernel<true>), dim3(grid), dim3(kBlock), 0, st, S.ev0, S.ready, 0, V, O, scans,
+                          (const unsigned long long *)offsets, B, shared_scan, inits, (float2 *)S.sorted, (PrepRec *)S.recs, (unsigned *)S.maps);
+  else
+    hipExtLaunchKernelGGL((ndt_order_kernel<false>), dim3(grid), dim3(kBlock), 0, st, S.ev0, S.ready, 0, V, O, scans,
+                          (const unsigned long long *)offsets, B, shared_scan, inits, (float2 *)S.sorted, (PrepRec *)S.recs, (unsigned *)S.maps);
+  HIP_TRY(ctx, hipGetLastError());
+  S.scans = scans; S.offsets = offsets; S.inits = inits; S.map = map; S.B = B; S.shared_scan = shared_scan; S.total_points = total_points;
+  S.min_bx = V.min_bx; S.min_by = V.min_by; S.div_x = V.div_x; S.div_y = V.div_y; S.inv_leaf = V.inv_leaf;
+  S.valid = true; S.timed = false;
+  ctx->prep_last ^= 1;
+  return NDT_OK;
+}
+
 int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, const uint64_t *offsets,
                         int B, size_t total_points, int shared_scan, const double *inits, ndt_result *out,
                         void *stream) {
@@ -876,13 +951,42 @@ int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, co
   hipStream_t st = stream ? (hipStream_t)stream : ctx->stream;
   // the map build may still be running on the stream of the context that built the map
   if (st != map->ctx->stream) HIP_TRY(ctx, hipStreamWaitEvent(st, map->ctx->evm1, 0));
+  // a set prepared for exactly this batch against exactly this grid?  (A map whose speculative grid turned out wrong has been
+  // queued again with another origin -- ndt_map_rebuild_end: NDT_REBUILT -- and the set no longer fits: the owners order their
+  // scans themselves, as without it.)
+  ndt_ctx::PrepSet *pset = nullptr;
+  for (ndt_ctx::PrepSet &S : ctx->prep) {
+    const MapView &V = map->view;
+    if (S.valid && S.scans == scans && S.offsets == offsets && S.inits == inits && S.map == map && S.B == B &&
+        S.shared_scan == shared_scan && S.total_points == total_points && S.min_bx == V.min_bx && S.min_by == V.min_by &&
+        S.div_x == V.div_x && S.div_y == V.div_y && S.inv_leaf == V.inv_leaf)
+      pset = &S;
+  }
+  if (pset) {
+    HIP_TRY(ctx, hipStreamWaitEvent(st, pset->ready, 0));
+    pset->valid = false;                           // one launch per prepared set (the caller prepares the next batch)
+  }
   int rc;
   if ((rc = scratch_begin(ctx, st))) return rc;
   ScratchScope scope(ctx, st);
   if ((rc = launch_align(ctx, map, st, scans, (const unsigned long long *)offsets, B, shared_scan, total_points, inits,
-                         out, nullptr, 0, nullptr, nullptr)))
+                         out, nullptr, 0, nullptr, nullptr, pset)))
     return rc;                                     // (scope: scratch_end all the same -- kernels may have been queued)
   return scope.close();
+}
+
+// ms of the order kernel of the prepared set the context's most recent launches used (0 when none); blocks until it has run
+int ndt_prepare_timing(ndt_ctx *ctx, float *order_ms) {
+  if (!ctx || !order_ms) return NDT_E_ARG;
+  *order_ms = 0.f;
+  for (ndt_ctx::PrepSet &S : ctx->prep) {
+    if (!S.ready || S.reader < 0) continue;
+    HIP_TRY(ctx, hipEventSynchronize(S.ready));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, S.ev0, S.ready));
+    if (ms > *order_ms) *order_ms = ms;
+  }
+  return NDT_OK;
 }
 
 }  // extern "C"

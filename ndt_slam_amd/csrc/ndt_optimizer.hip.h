@@ -339,6 +339,8 @@ __device__ __noinline__ void init_rest(AlignState &S, const OptParams &P, double
   angle_cs(P.snap_thresh, S.p[2], S.cj, S.sj);
   S.ch = S.cj; S.sh = S.sj;
   S.score = 0.0;
+  S.g[0] = S.g[1] = S.g[2] = 0.0;                  // (defined also in the record of a scan that never gets a pass: an empty one)
+  S.H[0] = S.H[1] = S.H[2] = S.H[3] = S.H[4] = S.H[5] = 0.0;
   S.need_tf = 0;
   S.phase = PH_INIT;
 }

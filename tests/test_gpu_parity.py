@@ -923,3 +923,74 @@ def test_wait_launch_orders_another_stream_behind_a_launch(gpu):
         cx.wait_launch(64)                                     # beyond the ring
     with pytest.raises(RuntimeError):
         cx.wait_launch(10)                                     # ten launches were made: 0 .. 9 exist
+
+
+def test_a_batch_prepared_ahead_gives_the_same_records(gpu, c1_world):
+    """ndt_align_batch_prepare_dev (round 5): optimiser start, window geometry and voxel order of a batch as a kernel of its own,
+    ahead of the launch.  Byte-identical records with and without it -- ragged batch with an empty scan and a scan beyond the
+    register-resident set-up (left to its owner) --, a prepared batch serves ONE launch, a different batch or a grid that has
+    changed in between is not served by it, and two batches can be prepared ahead on another stream."""
+    import torch
+    capi, ctx = gpu
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C3"]
+    m = synth.make_map(200_000, cfg["half"] / 2)
+    sf = synth.ScanFactory(m, cfg["half"] / 2, 3000)
+    parts, inits = [], []
+    for b in range(40):
+        sc, _, ini = sf.make(b)
+        if b == 7:
+            sc = sc[:0]                                               # an empty scan
+        if b == 11:
+            sc = np.concatenate([sc] * 4)[:11000]                     # beyond kSortRegs = 10240 points: the streaming set-up
+        parts.append(sc); inits.append(ini)
+    off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    scans = np.concatenate(parts); inits = np.array(inits)
+    dev = torch.device("cuda", 0)
+    prm = capi.default_params(resolution=cfg["resolution"])
+    gm = capi.Map(ctx, m, prm)
+    d_sc = torch.from_numpy(scans).to(dev); d_off = torch.from_numpy(off.astype(np.int64)).to(dev); d_in = torch.from_numpy(inits).to(dev)
+    B = len(inits)
+    args = (d_sc.data_ptr(), d_off.data_ptr(), B, len(scans), d_in.data_ptr())
+    out = [torch.zeros(B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev) for _ in range(4)]
+    side = torch.cuda.Stream(device=dev)
+
+    def rec(t):
+        torch.cuda.synchronize()
+        return np.frombuffer(t.cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
+    gm.align_batch_dev(*args, out[0].data_ptr())
+    plain = rec(out[0])
+    assert plain["status"][7] != 0 and np.all(np.delete(plain["status"], 7) == 0)
+    assert ctx.prepare_timing() == 0.0
+    gm.prepare_batch_dev(*args, stream=side.cuda_stream)              # on another stream: the launch waits for it
+    gm.align_batch_dev(*args, out[1].data_ptr())
+    prepared = rec(out[1])
+    assert prepared.tobytes() == plain.tobytes()
+    assert ctx.prepare_timing() > 0.0                                 # ... and it was used
+    # one launch per prepared batch: the next launch orders its scans itself, same records again
+    gm.align_batch_dev(*args, out[2].data_ptr())
+    assert rec(out[2]).tobytes() == plain.tobytes()
+    # a batch prepared for OTHER guesses is not used for these
+    d_in2 = d_in.clone(); d_in2[:, 0] += 0.05
+    gm.prepare_batch_dev(d_sc.data_ptr(), d_off.data_ptr(), B, len(scans), d_in2.data_ptr())
+    gm.align_batch_dev(*args, out[3].data_ptr())
+    assert rec(out[3]).tobytes() == plain.tobytes()
+    # ... and the batch it WAS prepared for gets it, also with a second batch prepared in between (two sets)
+    gm.prepare_batch_dev(*args)
+    o2 = torch.zeros_like(out[0])
+    gm.align_batch_dev(d_sc.data_ptr(), d_off.data_ptr(), B, len(scans), d_in2.data_ptr(), o2.data_ptr())
+    moved = rec(o2)
+    gm.align_batch_dev(*args, out[1].data_ptr())
+    assert rec(out[1]).tobytes() == plain.tobytes()
+    gm.align_batch_dev(d_sc.data_ptr(), d_off.data_ptr(), B, len(scans), d_in2.data_ptr(), o2.data_ptr())
+    assert rec(o2).tobytes() == moved.tobytes()
+    # a grid that changes between the two calls (the map rebuilt from a cloud with another bounding box): not used, same records
+    mv = m.copy(); mv[0] = m.min(axis=0) - np.float32(3 * cfg["resolution"])
+    gm.prepare_batch_dev(*args)
+    gm.rebuild(xy=mv)
+    fresh = capi.Map(ctx, mv, prm)
+    fresh.align_batch_dev(*args, out[2].data_ptr())
+    want = rec(out[2]).tobytes()
+    gm.align_batch_dev(*args, out[3].data_ptr())
+    assert rec(out[3]).tobytes() == want
+    fresh.close(); gm.close()
