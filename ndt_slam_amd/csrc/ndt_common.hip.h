@@ -109,6 +109,19 @@ __device__ __forceinline__ unsigned wave_incl_scan(unsigned x) {
   return x;
 }
 
+// min / max over the 64 lanes with DPP moves (row shifts, then the rows' results carried along): valid in lane 63
+__device__ __forceinline__ int wave_min_dpp(int x) {
+#define NDT_DPP_MIN(CTRL, ROWS) { const int t_ = __builtin_amdgcn_update_dpp(x, x, CTRL, ROWS, 0xF, false); x = t_ < x ? t_ : x; }
+  NDT_DPP_MIN(0x111, 0xF) NDT_DPP_MIN(0x112, 0xF) NDT_DPP_MIN(0x114, 0xF) NDT_DPP_MIN(0x118, 0xF) NDT_DPP_MIN(0x142, 0xA) NDT_DPP_MIN(0x143, 0xC)
+#undef NDT_DPP_MIN
+  return x;
+}
+__device__ __forceinline__ int wave_max_dpp(int x) {
+#define NDT_DPP_MAX(CTRL, ROWS) { const int t_ = __builtin_amdgcn_update_dpp(x, x, CTRL, ROWS, 0xF, false); x = t_ > x ? t_ : x; }
+  NDT_DPP_MAX(0x111, 0xF) NDT_DPP_MAX(0x112, 0xF) NDT_DPP_MAX(0x114, 0xF) NDT_DPP_MAX(0x118, 0xF) NDT_DPP_MAX(0x142, 0xA) NDT_DPP_MAX(0x143, 0xC)
+#undef NDT_DPP_MAX
+  return x;
+}
 __device__ __forceinline__ unsigned long long gld_u64(const unsigned long long *p) { return *(const NDT_GLOBAL unsigned long long *)p; }
 
 __device__ __forceinline__ float2 load_pt(const float *xy, size_t stride, size_t i) {
