@@ -626,7 +626,8 @@ __device__ __noinline__ bool sort_points(const MapView &M, const Tf32 &T0, const
 template <bool SSE, int PER>
 __device__ NDT_ORDER_INLINE void order_scan_regs(const MapView &M, const OptParams &P, const double *__restrict__ init,
                                              const float2 *__restrict__ scan, int n, Lds &L, uint4 *pool,
-                                             float2 *__restrict__ sp, u64 *stamps = nullptr, u64 t0s = 0) {
+                                             float2 *__restrict__ sp, u64 *stamps = nullptr, u64 t0s = 0,
+                                             ScanCtl *open_ctl = nullptr, unsigned *open_map = nullptr) {
   // The LDS pipe takes one wave instruction every ~4 cycles whatever its width (tools/repro/rates.hip), and these phases
   // are nothing but LDS traffic: counters, entries and places are moved 16 bytes at a time.
   constexpr int kRun = 20;                                             // counters per thread: five 16-byte words
@@ -737,6 +738,23 @@ __device__ NDT_ORDER_INLINE void order_scan_regs(const MapView &M, const OptPara
   }
   sync_lds();
   NDT_STAMP(stamps, t0s, 3);
+  // A launch with idle workgroups from the start (fewer scans than workgroups: one scan at a time, the reference's own use) opens
+  // the scan for joining HERE (round 5): the window's geometry and the marked cells are all a helper needs to stage its window --
+  // it does that while this workgroup still puts the points in order, and is registered before the first pass instead of
+  // 8 us behind it (the ordered copy is only read once a pass has been opened, behind this workgroup's own staging, whose
+  // last barrier drains the copy's stores).  Everything stored write-through and drained before the ticket, as in the kernel.
+  if (open_ctl) {
+    for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) st32(&open_map[i], wmap[i]);
+    if (threadIdx.x == 0) {
+      const Region r = L.RG;
+      st32((u32 *)&open_ctl->region[0], (u32)r.x0); st32((u32 *)&open_ctl->region[1], (u32)r.y0); st32((u32 *)&open_ctl->region[2], (u32)r.rw);
+      st32((u32 *)&open_ctl->region[3], (u32)r.rh); st32((u32 *)&open_ctl->region[4], (u32)r.cap); st32((u32 *)&open_ctl->region[5], 0u);
+      st32(&open_ctl->use_sorted, 1u);
+    }
+    drain_vmem();
+    __syncthreads();
+    if (threadIdx.x == 0) st64(&open_ctl->ticket, (u64)1 << 32);       // epoch 1: open for joining, nothing to compute yet
+  }
   // Places: the waves in turn (see the head of the routine).
   unsigned place[PER];
   for (int w = 0; w < kWaves; ++w) {
@@ -928,7 +946,7 @@ __device__ __forceinline__ const T *uniform_p(const T *p) {
 //   step  > 0: shared pass -- the wave takes units (j from the workgroup's LDS counter) 0 .. lead-1, then
 //              first + (j - lead) * step until they reach uend; totals to L.wpart (owner, vtot == nullptr) or, tagged,
 //              straight to the scan's unit totals in HBM (helper; lead = 0).
-template <bool SSE, bool INCL>
+template <bool SSE, bool INCL, bool CHK>
 __device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_in, u64 *vtot_in, unsigned tag_in, int lead_in) {
   const int first = (int)uniform_u((unsigned)first_in), step = (int)uniform_u((unsigned)step_in);
   const int uend = (int)uniform_u((unsigned)uend_in), lead = (int)uniform_u((unsigned)lead_in);
@@ -991,7 +1009,7 @@ __device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_i
     for (int k = kbeg; k < kend; ++k) {
       const float2 p2 = gld_f2(pts + min(base + (k + 2) * kBlock, last));
       if (base + k * kBlock >= n) p0.x = NAN;              // past the end: contributes nothing
-      eval_point<SSE, INCL>(M, W, etab, pp.T, p0.x, p0.y, pp.cj, pp.sj, pp.ch, pp.sh, A);
+      eval_point<SSE, INCL, CHK>(M, W, etab, pp.T, p0.x, p0.y, pp.cj, pp.sj, pp.ch, pp.sh, A);
       p0 = p1; p1 = p2;
       if (k + 1 == kb) {                                   // run q complete (uniform across the wave)
         const double a[12] = {A.e, A.g0, A.g1, A.g2, A.hxx, A.hxy, A.hxt, A.hyy, A.hyt, A.htt, (double)A.pairs, 0.0};
@@ -1086,7 +1104,7 @@ ndt_order_kernel(MapView M, OptParams P, const float *__restrict__ scans, const 
   }
 }
 
-template <bool SSE, bool INCL>
+template <bool SSE, bool INCL, bool CHK>
 __global__ void __launch_bounds__(kBlock)
 ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
                  const unsigned long long *__restrict__ offsets, int B, int shared_scan,
@@ -1142,6 +1160,8 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
     // latency of the scan's first touch
     const bool reg_path = n > 0 && sorted != nullptr && n <= kSortRegs;
     const bool prepared = reg_path && prep != nullptr && prep[b].ok != 0;        // (uniform: one word per scan)
+    // fewer scans than workgroups: idle workgroups from the start -- the scan is opened to them in the middle of its ordering
+    const bool early_open = allow_helpers != 0 && reg_path && !prepared && B < (int)gridDim.x;
     if (threadIdx.x == 0) {
       u32 expect = 0u;
       const bool won = !allow_helpers || b >= (int)gridDim.x || b == preclaimed ||
@@ -1187,7 +1207,9 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
         __syncthreads();
         NDT_STAMP(stamps, t0s, 0);
       } else if (reg_path) {
-        order_scan_regs<SSE, kSortRegs / kBlock>(L.M, L.P, inits + 3 * (size_t)b, scan, n, L, pool, sp, stamps, t0s); pts = sp;
+        order_scan_regs<SSE, kSortRegs / kBlock>(L.M, L.P, inits + 3 * (size_t)b, scan, n, L, pool, sp, stamps, t0s,
+                                                 early_open ? C : nullptr, early_open ? wantmap + (size_t)b * (kRegionCells / 32) : nullptr);
+        pts = sp;
       } else {
         compute_region<SSE>(L.M, L.S.T, scan, n, L);
         q1 = kProf ? wall_clock64() : 0;
@@ -1201,7 +1223,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       // stores: a wait for a load is a wait for every store issued before it), then the ordered copy on its way to memory.
       fill_window_plan(L.M, L, stamps, t0s);
       if (reg_path && !prepared) copy_out_ordered(pool, sp, n);
-      if (allow_helpers) {                         // helpers rebuild the same window from this bitmap
+      if (allow_helpers && !early_open) {          // helpers rebuild the same window from this bitmap
         const unsigned *wmap = reinterpret_cast<const unsigned *>(L.wpart);
         unsigned *gw = wantmap + (size_t)b * (kRegionCells / 32);
         for (int i = threadIdx.x; i < kRegionCells / 32; i += kBlock) st32(&gw[i], wmap[i]);
@@ -1216,13 +1238,13 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       //     staging, whose last barrier has drained the stores anyway -- the 2 us of waiting for the copy's 80 KB to land
       //     go by while the slot table is written (round 5).
       const bool late_publish = reg_path && B >= (int)gridDim.x;
-      if (allow_helpers && threadIdx.x == 0) {
+      if (allow_helpers && !early_open && threadIdx.x == 0) {
         const Region r = L.RG;
         st32((u32 *)&C->region[0], (u32)r.x0); st32((u32 *)&C->region[1], (u32)r.y0); st32((u32 *)&C->region[2], (u32)r.rw);
         st32((u32 *)&C->region[3], (u32)r.rh); st32((u32 *)&C->region[4], (u32)r.cap); st32((u32 *)&C->region[5], (u32)r.nspill);
         st32(&C->use_sorted, (pts != scan) ? 1u : 0u);
       }
-      if (allow_helpers && !late_publish) {
+      if (allow_helpers && !late_publish && !early_open) {
         drain_vmem();
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1305,12 +1327,12 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       const int nhelp = L.sflag[0];
       if (nhelp <= 0) {
         // solo pass: wave w computes its own units (w, 0..kSub-1) in one walk
-        pass_units<SSE, INCL>(wave, 0, kUnits, nullptr, 0u, 0);
+        pass_units<SSE, INCL, CHK>(wave, 0, kUnits, nullptr, 0u, 0);
       } else {
         // this workgroup's units 0 .. kOwnerLead-1 and kOwnerLead + j*(nhelp+1), handed to its waves from an LDS counter
         ++epoch;
         pass_h = nhelp;
-        pass_units<SSE, INCL>(kOwnerLead, nhelp + 1, kUnits, nullptr, 0u, kOwnerLead);
+        pass_units<SSE, INCL, CHK>(kOwnerLead, nhelp + 1, kUnits, nullptr, 0u, kOwnerLead);
         if (kProf && prof) ts2 = wall_clock64();
         // the helpers' units: every thread polls the words it will copy (24 per unit) until they carry this epoch's
         // tag (every counted helper is polling the epoch word or computing)
@@ -1604,7 +1626,7 @@ ndt_align_kernel(MapView M, OptParams P, const float *__restrict__ scans,
       const int h = (int)((word >> 16) & 0xFFu), ubeg = (int)(word & 0xFFu), uend = (int)((word >> 8) & 0xFFu);
       if (rank < h) {
         // this workgroup's units ubeg + rank+1 + j*(h+1), handed to its waves from an LDS counter
-        pass_units<SSE, INCL>(ubeg + (rank + 1), h + 1, uend, vtot, ep, 0);
+        pass_units<SSE, INCL, CHK>(ubeg + (rank + 1), h + 1, uend, vtot, ep, 0);
       }
       __syncthreads();                                       // L.jnext / L.PP are rewritten by wave 0 in the next turn
       if (kProf && prof && threadIdx.x == 0 && rank < 6 && rank < h && ep - 2u < (unsigned)kProfPasses)

@@ -302,13 +302,16 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   // timing: the events ride on the kernels' own dispatch packets (hipExtLaunchKernelGGL: start / stop of that kernel) -- an
   // event RECORD is a packet of its own between two kernels, three of them per launch cost the stream 6-10 us
   hipEvent_t *evr = ctx->ev_ring + 3 * (ctx->launches % ndt_ctx::kTimeRing);
-#define NDT_LAUNCH(S_, I_)                                                                                          \
-  hipExtLaunchKernelGGL((ndt_align_kernel<S_, I_>), dim3(grid), dim3(kBlock), 0, st, evr[0], evr[1], 0, V, O, scans, \
+  // (the pair check left out where it cannot fire -- accumulate_pair -- in the preset's own instantiation only)
+  const bool chk = !(V.e_hi > 1.0 + 1e-6);
+#define NDT_LAUNCH(S_, I_, C_)                                                                                          \
+  hipExtLaunchKernelGGL((ndt_align_kernel<S_, I_, C_>), dim3(grid), dim3(kBlock), 0, st, evr[0], evr[1], 0, V, O, scans, \
                         offsets, B, shared_scan, inits, out, trace, trace_cap, trace_rows, sorted, ws, helpers, prof, prep, prep_map)
-  if (sse && incl) NDT_LAUNCH(true, true);
-  else if (sse)    NDT_LAUNCH(true, false);
-  else if (incl)   NDT_LAUNCH(false, true);
-  else             NDT_LAUNCH(false, false);
+  if (sse && incl)      NDT_LAUNCH(true, true, true);
+  else if (sse && !chk) NDT_LAUNCH(true, false, false);
+  else if (sse)         NDT_LAUNCH(true, false, true);
+  else if (incl)        NDT_LAUNCH(false, true, true);
+  else                  NDT_LAUNCH(false, false, true);
 #undef NDT_LAUNCH
   // From here on a kernel that reads the map and the context's scratch is queued: whatever happens below, the launch is
   // entered in the context's ring (its last event recorded) and in the map's list of readers, so that a later call on another

@@ -40,8 +40,16 @@ __device__ __forceinline__ double exp_neg(double x, const double *__restrict__ t
 #endif
   double r = __builtin_fma(-t, 0x1.62e42fefa0000p-7, x);    // ln2/64, high part (exact product)
   r = __builtin_fma(-t, 0x1.cf79abc9e3b3ap-46, r);          // low part
+#ifdef NDT_EXP_PLAIN
   double p = __builtin_fma(r, 1.0 / 120.0, 1.0 / 24.0);
   p = __builtin_fma(r, p, 1.0 / 6.0);
+#else
+  // (the same two fused multiply-adds, spelled as three-address v_fma_f64: left to itself the compiler keeps 1/24 and 1/6 in
+  //  registers that share their low word and turns each step into v_mov + v_fmac -- three extra instructions per pair)
+  double p, c4 = 1.0 / 24.0, c3 = 1.0 / 6.0, c5 = 1.0 / 120.0;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(r), "v"(c5), "v"(c4));
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(r), "v"(p), "v"(c3));
+#endif
   p = __builtin_fma(r, p, 0.5);
   p = __builtin_fma(p, r * r, r);                           // exp(r) - 1
   return ldexp(__builtin_fma(sc, p, sc), n >> 6);
@@ -85,6 +93,12 @@ struct PointAcc { double se, a0, a1, b00, b01, b11; };
 // updateDerivatives' error check `d2 e > 1 || d2 e < 0 || NaN` as one comparison: e >= 0 always (exp_neg), so for d2 > 0
 // the pair is dropped exactly when e > e_hi, e_hi = the largest double with fl(d2 * e_hi) <= 1 (found on the host,
 // MapView::e_hi; -1 when d2 < 0: every pair with e > 0 is dropped, +inf when d2 is 0 or NaN).
+// CHK = false (round 5): the check left out where it cannot fire.  The map build hands out inverse covariances that are positive
+// semi-definite by construction (closed-form eigen-decomposition, eigenvalues floored at eig_mult x the larger one; a rejected
+// voxel has Sigma^-1 = 0), so m = q^T Sigma^-1 q >= -(rounding), e = exp(-d2 m / 2) <= 1 + 1e-12 for d2 > 0 -- and the launch
+// picks CHK = false only when e_hi > 1 + 1e-6 (d2 < 1 - 1e-6: the 0.5 m preset has d2 = 0.756, e_hi = 1.32).  A comparison and
+// two selects fewer in a 56-instruction loop that runs 3.7 times per point.
+template <bool CHK = true>
 __device__ __forceinline__ void accumulate_pair(double e_hi, double nd2, double nd2h, const double *__restrict__ etab,
                                                 double XT, double YT, const CellRec &c, PointAcc &S) {
   const double q0 = XT - c.mx, q1 = YT - c.my;
@@ -92,7 +106,7 @@ __device__ __forceinline__ void accumulate_pair(double e_hi, double nd2, double 
   const double u1 = __builtin_fma(c.i11, q1, c.i01 * q0);
   const double m = __builtin_fma(q1, u1, q0 * u0);
   double e = exp_neg(nd2h * m, etab);                          // (-d2 m) / 2, the halving is exact
-  if (e > e_hi) e = 0.0;                                       // updateDerivatives error check
+  if (CHK && e > e_hi) e = 0.0;                                // updateDerivatives error check
   const double v0 = nd2 * u0, v1 = nd2 * u1;
   S.se += e;
   S.a0 = __builtin_fma(e, u0, S.a0);
@@ -125,7 +139,7 @@ __device__ __forceinline__ void finish_point(float x, float y, double cj, double
 // Fast path (window holds every occupied voxel, point's 3x3 neighbourhood inside it): slot
 // numbers, centroids and records all come from LDS.  Otherwise the same arithmetic reads the
 // global centroid grid / record array.
-template <bool SSE, bool INCL>
+template <bool SSE, bool INCL, bool CHK = true>
 __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
                                            const double *__restrict__ etab, const Tf32 &T, float x,
                                            float y, double cj, double sj, double ch, double sh, Acc &A) {
@@ -142,6 +156,7 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
   const int clx = min(max(lx, 1), max(R.rw - 2, 1)), cly = min(max(ly, 1), max(R.rh - 2, 1));
   const unsigned short *srow = W.slot + (__mul24(cly - 1, R.rw) + (clx - 1));
   const int rw3 = R.rw - 3;                    // slot of neighbour k = 3 r + q: srow[r * rw + q] = srow[r * (rw - 3) + k]
+  const int rw3x2 = 2 * rw3;                   // (in bytes)
   unsigned mask = 0;
   float lowx = INFINITY;                       // -inf <=> one of the nine voxels is occupied but not resident
   // (the nine slot numbers first, then the nine centroids: left to itself the scheduler waited for the first slot before
@@ -175,10 +190,11 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
     do {
       const int k = __builtin_ctz(mask);
       mask &= mask - 1;
-      const int r = __mul24(k, 11) >> 5;                       // k / 3 for k in [0, 9)
-      const CellEntry &E = W.ent[srow[__mul24(r, rw3) + k]];
+      const unsigned k2 = 2u * (unsigned)k;
+      const int r = (int)__builtin_amdgcn_ubfe(0x2A540u, k2, 2u);                  // k / 3 for k in [0, 9): two bits per k, one v_bfe_u32
+      const CellEntry &E = W.ent[*reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(srow) + (__mul24(r, rw3x2) + (int)k2))];
       CellRec c; c.mx = E.mx; c.my = E.my; c.i00 = E.i00; c.i01 = E.i01; c.i11 = E.i11;
-      accumulate_pair(M.e_hi, nd2, nd2h, etab, XT, YT, c, S);
+      accumulate_pair<CHK>(M.e_hi, nd2, nd2h, etab, XT, YT, c, S);
     } while (mask);
     finish_point(x, y, cj, sj, ch, sh, S, A);
     return;
@@ -202,7 +218,7 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
   do {
     const int k = __builtin_ctz(mask);
     mask &= mask - 1;
-    accumulate_pair(M.e_hi, nd2, nd2h, etab, XT, YT, load_rec_global(M, base, k), S);
+    accumulate_pair<CHK>(M.e_hi, nd2, nd2h, etab, XT, YT, load_rec_global(M, base, k), S);
   } while (mask);
   finish_point(x, y, cj, sj, ch, sh, S, A);
 }
