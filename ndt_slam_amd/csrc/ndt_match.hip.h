@@ -1003,12 +1003,15 @@ __device__ NDT_PASS_INLINE void pass_units(int first_in, int step_in, int uend_i
     const int kbeg = kstart(q0), kend = kstart(q1);
     const int base = w * 64 + lane;
     Acc A = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0u};
-    float2 p0 = gld_f2(pts + min(base + kbeg * kBlock, last)), p1 = gld_f2(pts + min(base + (kbeg + 1) * kBlock, last));
+    // (loads at a 32-bit byte offset from the uniform base: one shift per address instead of a sign extension + 64-bit add)
+    float2 p0 = gld_f2_at(pts, (unsigned)min(base + kbeg * kBlock, last) * 8u), p1 = gld_f2_at(pts, (unsigned)min(base + (kbeg + 1) * kBlock, last) * 8u);
     int q = q0, kb = kstart(q0 + 1);                       // end of the current run
 #pragma nounroll
     for (int k = kbeg; k < kend; ++k) {
-      const float2 p2 = gld_f2(pts + min(base + (k + 2) * kBlock, last));
-      if (base + k * kBlock >= n) p0.x = NAN;              // past the end: contributes nothing
+      const float2 p2 = gld_f2_at(pts, (unsigned)min(base + (k + 2) * kBlock, last) * 8u);
+      if ((k + 1) * kBlock > n) {                          // (uniform) only the scan's last round has lanes past the end
+        if (base + k * kBlock >= n) p0.x = NAN;            // past the end: contributes nothing
+      }
       eval_point<SSE, INCL, CHK>(M, W, etab, pp.T, p0.x, p0.y, pp.cj, pp.sj, pp.ch, pp.sh, A);
       p0 = p1; p1 = p2;
       if (k + 1 == kb) {                                   // run q complete (uniform across the wave)

@@ -32,8 +32,19 @@ struct Window {
 __constant__ double c_exp2_tab[64];
 __device__ __forceinline__ double exp_neg(double x, const double *__restrict__ tab) {
   x = fmax(x, -800.0);
+#ifdef NDT_EXP_RINT
   const double t = rint(x * 92.332482616893657);            // 64 / ln 2
   const int n = (int)t;
+#else
+  // t = the integer nearest to x * 64 / ln 2, by adding and taking away 1.5 * 2^52 (|x * 64 / ln 2| < 2^17): the sum's low word IS
+  // that integer (two's complement), so neither a rounding nor a conversion instruction is needed (round 5: one instruction
+  // fewer per pair; the product is rounded once, inside the fma, where rint (x * c) rounded twice -- the two differ only when
+  // x * c lies within an ulp of a half-integer, and then by one table step whose result agrees to the last bit or two)
+  const double big = 6755399441055744.0;
+  const double sum = __builtin_fma(x, 92.332482616893657, big);
+  const double t = sum - big;
+  const int n = (int)(unsigned)__double_as_longlong(sum);
+#endif
   const double sc = tab[n & 63];
 #ifndef NDT_NO_EXP_SCHED
   __builtin_amdgcn_sched_barrier(0);                        // issue the table read BEFORE the polynomial (the scheduler put it behind: a full LDS latency exposed per pair)
@@ -47,8 +58,10 @@ __device__ __forceinline__ double exp_neg(double x, const double *__restrict__ t
   // (the same two fused multiply-adds, spelled as three-address v_fma_f64: left to itself the compiler keeps 1/24 and 1/6 in
   //  registers that share their low word and turns each step into v_mov + v_fmac -- three extra instructions per pair)
   double p, c4 = 1.0 / 24.0, c3 = 1.0 / 6.0, c5 = 1.0 / 120.0;
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(r), "v"(c5), "v"(c4));
-  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(r), "v"(p), "v"(c3));
+  //  (1/120 and 1/6 as scalar operands -- one per instruction is allowed -- 1/24 in a vector register: 1/24 and 1/6 in vector
+  //   registers share their low word in the compiler's hands, which costs a v_mov per pair to put 1/6 together)
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(r), "s"(c5), "v"(c4));
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(r), "v"(p), "s"(c3));
 #endif
   p = __builtin_fma(r, p, 0.5);
   p = __builtin_fma(p, r * r, r);                           // exp(r) - 1
@@ -175,11 +188,13 @@ __device__ __forceinline__ void eval_point(const MapView &M, const Window &W,
 #ifndef NDT_NO_PROBE_SCHED
   __builtin_amdgcn_sched_barrier(0);
 #endif
+  // (-inf centroids -- occupied voxels without an LDS record -- exist only in a window that spilled: uniform)
+  if (R.nspill > 0) {
 #pragma unroll
-  for (int k = 0; k < 9; ++k) {
-    lowx = fminf(lowx, cc[k].x);
-    mask |= in_radius<INCL>(M.r2, xt, yt, cc[k]) << k;
+    for (int k = 0; k < 9; ++k) lowx = fminf(lowx, cc[k].x);
   }
+#pragma unroll
+  for (int k = 0; k < 9; ++k) mask |= in_radius<INCL>(M.r2, xt, yt, cc[k]) << k;
   const double nd2 = -M.d2, nd2h = nd2 * 0.5;
   if (inwin & (lowx != -INFINITY)) {
     if (!mask) return;
