@@ -474,7 +474,8 @@ fitness_reduce_kernel(const unsigned long long *__restrict__ offsets, int B, int
   // the last kernel of a launch also clears the match kernel's control words and epoch-tagged words for the next
   // launch (one kernel fewer between two launches than a memset in front of each)
   for (unsigned i = blockIdx.x * kFitBlock + threadIdx.x; i < n_ws_words; i += gridDim.x * kFitBlock) ws_words[i] = uint4{0u, 0u, 0u, 0u};
-  __shared__ double U[kFitSub * (kFitBlock / 64) * 2];
+  __shared__ double U[2][kFitSub * (kFitBlock / 64)];        // [sum | count][unit]
+  __shared__ double Tt[2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, base = wave * 64 + lane;
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
@@ -486,26 +487,36 @@ fitness_reduce_kernel(const unsigned long long *__restrict__ offsets, int B, int
     for (int q = 0; q < kFitSub; ++q) {
       const int k0 = min(per_lane, q * run), k1 = min(per_lane, (q + 1) * run);
       double fsum = 0.0, fcnt = 0.0;
-      for (int k = k0; k < k1; ++k) {
-        const int i = base + k * kFitBlock;
-        if (i >= n) break;
-        const float v = f[i];
-        if (v < INFINITY) { fsum += (double)v; fcnt += 1.0; }
+      // (eight loads in flight, then their additions in order)
+      for (int k = k0; k < k1; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + (k + u) * kFitBlock;
+          v[u] = (k + u < k1 && i < n) ? f[i] : INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (v[u] < INFINITY) { fsum += (double)v[u]; fcnt += 1.0; }
       }
       fsum = wave_sum(fsum); fcnt = wave_sum(fcnt);
-      if (lane == 0) { U[(q * (kFitBlock / 64) + wave) * 2] = fsum; U[(q * (kFitBlock / 64) + wave) * 2 + 1] = fcnt; }
+      if (lane == 0) { U[0][q * (kFitBlock / 64) + wave] = fsum; U[1][q * (kFitBlock / 64) + wave] = fcnt; }
     }
     __syncthreads();
-    if (threadIdx.x < 2) {                       // units in order: groups of 16, then the groups
+    if (threadIdx.x < 2) {                       // units in order: groups of 16, then the groups (all 64 values read first: the
+      double u[kFitSub * 16];                    //  additions are a chain as it is, the LDS reads need not be one too)
+#pragma unroll
+      for (int v = 0; v < kFitSub * 16; ++v) u[v] = U[threadIdx.x][v];
       double total = 0.0;
+#pragma unroll
       for (int g = 0; g < kFitSub; ++g) {
         double part = 0.0;
-        for (int v = 16 * g; v < 16 * g + 16; ++v) part += U[v * 2 + threadIdx.x];
+#pragma unroll
+        for (int v = 16 * g; v < 16 * g + 16; ++v) part += u[v];
         total = g ? total + part : part;
       }
-      U[threadIdx.x] = total;
+      Tt[threadIdx.x] = total;
     }
     __syncthreads();
-    if (threadIdx.x == 0) results[b].fitness = (n > 0 && U[1] > 0) ? U[0] / U[1] : DBL_MAX;
+    if (threadIdx.x == 0) results[b].fitness = (n > 0 && Tt[1] > 0) ? Tt[0] / Tt[1] : DBL_MAX;
   }
 }
