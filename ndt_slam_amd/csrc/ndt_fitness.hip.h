@@ -355,6 +355,36 @@ __device__ __forceinline__ float nearest_sq(const MapView &M, float qx, float qy
 // and fitness_far_kernel finishes them, 64 queries of ONE kind per wave.  With phase 3 inline a wave walks the rings of its
 // farthest lane while the others wait: on configs[4]'s seeds the longest lane of a wave needs 31 rounds of dependent loads,
 // the average lane 8, and less than half the lanes need the phase at all.
+// The mean of a match's distances, and the order it is summed in (round 5; the same for every launch shape and for both
+// forms of the fitness kernels): the match's points in chunks of 64 consecutive points of the ordered copy -- chunk c's
+// sum is the wave butterfly (wave_sum) over its 64 values, points without a distance adding 0 -- then lane l of ONE wave
+// adds the chunks l, l + 64, l + 128 ... one after the other, and the wave butterfly adds the lanes.  Counts are whole
+// numbers however they are added.  A chunk's {sum, count} is 16 bytes in the launch's FitPart array: written by the wave
+// that searched the chunk (fitness_points_kernel, scans of their own) or summed it (fitness_reduce_kernel), read by the
+// wave that closes the match.
+struct FitPart { double sum, cnt; };
+__device__ __forceinline__ size_t fit_part_of(int b, int n, unsigned long long o0, int shared_scan) {     // first chunk of match b
+  return shared_scan ? (size_t)b * (size_t)((n + 63) >> 6) : (size_t)(o0 >> 6) + (size_t)b;
+}
+// one whole wave: the match's fitness from its chunks
+__device__ __forceinline__ void fitness_close_match(const FitPart *__restrict__ part, int n, ndt_result *R) {
+  const int lane = threadIdx.x & 63, nch = (n + 63) >> 6;
+  double s = 0.0, c = 0.0;
+  for (int k = lane; k < nch; k += 4 * 64) {                    // (four loads of each kind in flight; added in order)
+    double vs[4], vc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool in = k + 64 * u < nch;
+      vs[u] = in ? gld_d(&part[k + 64 * u].sum) : 0.0;
+      vc[u] = in ? gld_d(&part[k + 64 * u].cnt) : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) if (k + 64 * u < nch) { s += vs[u]; c += vc[u]; }
+  }
+  s = wave_sum(s); c = wave_sum(c);
+  if (lane == 0) R->fitness = (n > 0 && c > 0) ? s / c : DBL_MAX;
+}
+
 // XCD-aware numbering of the fitness kernels' workgroups (round 5).  The dispatcher deals consecutive workgroups out to the
 // eight XCDs in turn, each with an L2 of its own; a (gx, B) grid with the match's blocks along x therefore spread every match
 // over all eight L2s: its ordered copy, its ~300 KB of buckets and their offsets were pulled into each of them.  Now the grid
@@ -372,7 +402,8 @@ template <bool SSE, bool DEFER>
 __global__ void __launch_bounds__(256, NDT_FIT_OCC)
 fitness_points_kernel(MapView M, const float *__restrict__ scans, const unsigned long long *__restrict__ offsets, int B,
                       int shared_scan, const float2 *__restrict__ sorted, const ndt_result *__restrict__ results,
-                      float *__restrict__ fit, unsigned *__restrict__ far_idx, unsigned *__restrict__ far_n, int gx) {
+                      float *__restrict__ fit, unsigned *__restrict__ far_idx, unsigned *__restrict__ far_n, int gx,
+                      FitPart *__restrict__ parts) {
   __shared__ RingLds ring[256 / 64];
   int b, bx;
   if (!fit_block_of(gx, B, b, bx)) return;
@@ -385,7 +416,8 @@ fitness_points_kernel(MapView M, const float *__restrict__ scans, const unsigned
     const bool use_sorted = sorted != nullptr && !(R->flags & NDT_FLAG_UNSORTED);
     const size_t slot = shared_scan ? (size_t)b * (size_t)n : (size_t)o0;
     const float2 *pts = use_sorted ? sorted + slot : reinterpret_cast<const float2 *>(scans) + o0;
-    float *out = fit + slot;
+    float *out = DEFER ? fit + slot : nullptr;
+    FitPart *part = DEFER ? nullptr : parts + fit_part_of(b, n, o0, shared_scan);
     // whole waves stay together (the ring-1 phase is a wave's joint work): lanes past the end carry no query
     for (int i0 = bx * (int)blockDim.x + (int)(threadIdx.x & ~63u); i0 < n; i0 += gx * (int)blockDim.x) {
       const int i = i0 + (int)(threadIdx.x & 63u);
@@ -415,7 +447,15 @@ fitness_points_kernel(MapView M, const float *__restrict__ scans, const unsigned
       } else {
         best = nearest_far(M, qx, qy, S, best);
       }
-      if (i < n) out[i] = live ? best : INFINITY;
+      if (DEFER) {
+        if (i < n) out[i] = live ? best : INFINITY;
+      } else {
+        // the distances of this chunk of 64 points never leave the wave: their sum and their number do (i0 is a multiple of 64)
+        const bool in = live && best < INFINITY;
+        const double t = wave_sum(in ? (double)best : 0.0);
+        const int c = __popcll(__ballot(in));
+        if ((threadIdx.x & 63u) == 0u) part[i0 >> 6] = FitPart{t, (double)c};
+      }
     }
   }
 }
@@ -466,57 +506,53 @@ fitness_far_kernel(MapView M, const float *__restrict__ scans, const unsigned lo
   }
 }
 
-constexpr int kFitBlock = 1024, kFitSub = 4;     // = kBlock, kSub of the match kernel: the order of the sum
+// The last kernel of a launch.  SUM (DEFER launches: the distances are complete only behind fitness_far_kernel): a
+// workgroup per match sums them into the match's chunks, and its first wave closes the match.  !SUM: the chunks are there
+// (fitness_points_kernel), a wave per match closes it.
+constexpr int kFitBlock = 1024;
+template <bool SUM>
 __global__ void __launch_bounds__(kFitBlock)
 fitness_reduce_kernel(const unsigned long long *__restrict__ offsets, int B, int shared_scan,
-                      const float *__restrict__ fit, ndt_result *__restrict__ results,
+                      const float *__restrict__ fit, ndt_result *__restrict__ results, FitPart *parts,
                       uint4 *__restrict__ ws_words, unsigned n_ws_words) {
-  // the last kernel of a launch also clears the match kernel's control words and epoch-tagged words for the next
-  // launch (one kernel fewer between two launches than a memset in front of each)
+  // it also clears the match kernel's control words and epoch-tagged words for the next launch (one kernel fewer between
+  // two launches than a memset in front of each)
   for (unsigned i = blockIdx.x * kFitBlock + threadIdx.x; i < n_ws_words; i += gridDim.x * kFitBlock) ws_words[i] = uint4{0u, 0u, 0u, 0u};
-  __shared__ double U[2][kFitSub * (kFitBlock / 64)];        // [sum | count][unit]
-  __shared__ double Tt[2];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, base = wave * 64 + lane;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (!SUM) {
+    for (int b = blockIdx.x * (kFitBlock / 64) + wave; b < B; b += gridDim.x * (kFitBlock / 64)) {
+      const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
+      const unsigned long long o1 = shared_scan ? offsets[1] : offsets[b + 1];
+      const int n = (int)(o1 - o0);
+      fitness_close_match(parts + fit_part_of(b, n, o0, shared_scan), n, results + b);
+    }
+    return;
+  }
   for (int b = blockIdx.x; b < B; b += gridDim.x) {
     const unsigned long long o0 = shared_scan ? offsets[0] : offsets[b];
     const unsigned long long o1 = shared_scan ? offsets[1] : offsets[b + 1];
-    const int n = (int)(o1 - o0);
+    const int n = (int)(o1 - o0), nch = (n + 63) >> 6;
     const float *f = fit + (shared_scan ? (size_t)b * (size_t)n : (size_t)o0);
-    const int per_lane = (n + kFitBlock - 1) / kFitBlock, run = (per_lane + kFitSub - 1) / kFitSub;
-    __syncthreads();
-    for (int q = 0; q < kFitSub; ++q) {
-      const int k0 = min(per_lane, q * run), k1 = min(per_lane, (q + 1) * run);
-      double fsum = 0.0, fcnt = 0.0;
-      // (eight loads in flight, then their additions in order)
-      for (int k = k0; k < k1; k += 8) {
-        float v[8];
+    FitPart *part = parts + fit_part_of(b, n, o0, shared_scan);
+    for (int c0 = wave; c0 < nch; c0 += 4 * (kFitBlock / 64)) {   // (four chunks of the wave in flight)
+      float v[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int i = base + (k + u) * kFitBlock;
-          v[u] = (k + u < k1 && i < n) ? f[i] : INFINITY;
+      for (int u = 0; u < 4; ++u) {
+        const int i = (c0 + u * (kFitBlock / 64)) * 64 + lane;
+        v[u] = i < n ? f[i] : INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * (kFitBlock / 64);
+        if (c < nch) {                                           // (wave-uniform)
+          const bool in = v[u] < INFINITY;
+          const double t = wave_sum(in ? (double)v[u] : 0.0);
+          const int k = __popcll(__ballot(in));
+          if (lane == 0) part[c] = FitPart{t, (double)k};
         }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (v[u] < INFINITY) { fsum += (double)v[u]; fcnt += 1.0; }
       }
-      fsum = wave_sum(fsum); fcnt = wave_sum(fcnt);
-      if (lane == 0) { U[0][q * (kFitBlock / 64) + wave] = fsum; U[1][q * (kFitBlock / 64) + wave] = fcnt; }
     }
-    __syncthreads();
-    if (threadIdx.x < 2) {                       // units in order: groups of 16, then the groups (all 64 values read first: the
-      double u[kFitSub * 16];                    //  additions are a chain as it is, the LDS reads need not be one too)
-#pragma unroll
-      for (int v = 0; v < kFitSub * 16; ++v) u[v] = U[threadIdx.x][v];
-      double total = 0.0;
-#pragma unroll
-      for (int g = 0; g < kFitSub; ++g) {
-        double part = 0.0;
-#pragma unroll
-        for (int v = 16 * g; v < 16 * g + 16; ++v) part += u[v];
-        total = g ? total + part : part;
-      }
-      Tt[threadIdx.x] = total;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) results[b].fitness = (n > 0 && Tt[1] > 0) ? Tt[0] / Tt[1] : DBL_MAX;
+    __syncthreads();                                             // (the chunks of this workgroup's waves: stored, then read by wave 0)
+    if (wave == 0) fitness_close_match(part, n, results + b);
   }
 }

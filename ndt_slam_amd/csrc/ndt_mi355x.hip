@@ -78,7 +78,8 @@ struct ndt_ctx {
   void *d_trace = nullptr; size_t d_trace_cap = 0;
   void *d_rows = nullptr; size_t d_rows_cap = 0;
   void *d_sorted = nullptr; size_t d_sorted_cap = 0;   // cell-ordered copy of the scans
-  void *d_fit = nullptr; size_t d_fit_cap = 0;         // squared distance to the nearest map point, per scan point
+  void *d_fit = nullptr; size_t d_fit_cap = 0;         // squared distance to the nearest map point, per scan point (shared_scan launches)
+  void *d_fit_part = nullptr; size_t d_fit_part_cap = 0;   // FitPart per chunk of 64 scan points (ndt_fitness.hip.h)
   void *d_far = nullptr; size_t d_far_cap = 0;         // deferred far phase of the fitness search: per match two counts, then the lists
   void *d_ws = nullptr; size_t d_ws_cap = 0;           // WsHeader + ScanCtl[B] + chunk totals
   void *d_pf = nullptr; size_t d_pf_cap = 0;           // pre-filter: filtered points at the raw offsets + counts
@@ -279,7 +280,7 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   // fitness score; when every match uses scan 0 each match has its own slot of the scan's size
   const size_t slots = (shared_scan ? (size_t)B : (size_t)1) * total_points;
   if ((rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, slots * sizeof(float2) + 16))) return rc;
-  if ((rc = ensure(ctx, &ctx->d_fit, &ctx->d_fit_cap, slots * sizeof(float) + 16))) return rc;
+  if (shared_scan && (rc = ensure(ctx, &ctx->d_fit, &ctx->d_fit_cap, slots * sizeof(float) + 16))) return rc;   // (scans of their own: chunk sums only, d_fit_part)
   float2 *sorted = pset ? (float2 *)pset->sorted : (float2 *)ctx->d_sorted;      // (a prepared batch: its ordered copies are in its own set)
   const PrepRec *prep = pset ? (const PrepRec *)pset->recs : nullptr;
   const unsigned *prep_map = pset ? (const unsigned *)pset->maps : nullptr;
@@ -287,6 +288,9 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   // (every allocation of the launch in front of its first kernel: nothing below can fail for want of memory once work is queued)
   const size_t far_cnt_bytes = ((size_t)B * 2 * sizeof(unsigned) + 15) & ~(size_t)15;
   if (shared_scan && (rc = ensure(ctx, &ctx->d_far, &ctx->d_far_cap, far_cnt_bytes + slots * sizeof(unsigned) + 16))) return rc;
+  // the chunk sums of the fitness kernels (FitPart, a chunk = 64 points; a match's chunks start at fit_part_of)
+  if ((rc = ensure(ctx, &ctx->d_fit_part, &ctx->d_fit_part_cap, (slots / 64 + (size_t)B + 1) * sizeof(FitPart)))) return rc;
+  FitPart *parts = (FitPart *)ctx->d_fit_part;
   // control words: zero before every launch -- by the last kernel of the previous launch of this context
   // (fitness_reduce_kernel), or by a memset when that did not cover enough
   if (ctx->ws_clean < zero_bytes) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ws, 0, zero_bytes, st));
@@ -343,16 +347,22 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
       const size_t cnt_bytes = far_cnt_bytes;
       unsigned *far_n = (unsigned *)ctx->d_far, *far_idx = (unsigned *)((unsigned char *)ctx->d_far + cnt_bytes);
       { hipError_t e = hipMemsetAsync(far_n, 0, cnt_bytes, st); if (e != hipSuccess) return entered(fail(ctx, NDT_E_HIP, std::string("launch_align: hipMemsetAsync: ") + hipGetErrorString(e))); }
-      if (sse) fitness_points_kernel<true, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
-      else     fitness_points_kernel<false, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
+      if (sse) fitness_points_kernel<true, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx, nullptr);
+      else     fitness_points_kernel<false, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx, nullptr);
       if (sse) fitness_far_kernel<true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
       else     fitness_far_kernel<false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
+      hipExtLaunchKernelGGL(fitness_reduce_kernel<true>, dim3(std::min(B, 4 * ctx->num_cus)), dim3(kFitBlock), 0, st, nullptr, evr[2], 0,
+                            offsets, B, shared_scan, (const float *)fit, out, parts, (uint4 *)ws, (unsigned)(zero_bytes / 16));
     } else {
-      if (sse) fitness_points_kernel<true, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr, (int)gx);
-      else     fitness_points_kernel<false, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr, (int)gx);
+      // scans of their own: the search kernel leaves a {sum, count} per chunk of 64 points instead of a distance per point
+      if (sse) fitness_points_kernel<true, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr, (int)gx, parts);
+      else     fitness_points_kernel<false, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr, (int)gx, parts);
+      // (a wave per match; at least as many workgroups as clear the control words with one store per thread, a CU each at most)
+      const size_t close_wgs = std::max<size_t>(((size_t)B + kFitBlock / 64 - 1) / (kFitBlock / 64),
+                                                std::min<size_t>((size_t)ctx->num_cus, (zero_bytes / 16 + kFitBlock - 1) / kFitBlock));
+      hipExtLaunchKernelGGL(fitness_reduce_kernel<false>, dim3((unsigned)close_wgs), dim3(kFitBlock), 0, st, nullptr, evr[2], 0,
+                            offsets, B, shared_scan, (const float *)nullptr, out, parts, (uint4 *)ws, (unsigned)(zero_bytes / 16));
     }
-    hipExtLaunchKernelGGL(fitness_reduce_kernel, dim3(std::min(B, 4 * ctx->num_cus)), dim3(kFitBlock), 0, st, nullptr, evr[2], 0,
-                          offsets, B, shared_scan, (const float *)fit, out, (uint4 *)ws, (unsigned)(zero_bytes / 16));
   }
   {
     hipError_t e = hipGetLastError();
@@ -497,7 +507,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
     if (S.maps) e = hipFree(S.maps);
   }
   if (c->h_mm) e = hipHostFree(c->h_mm);
-  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_fit, c->d_far, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
+  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_fit, c->d_far, c->d_fit_part, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
   delete c;
