@@ -383,6 +383,43 @@ def test_batch_fitness_ring_phase_matches_the_single_query_search(gpu, oracle):
             assert r["fitness"] == pytest.approx(om.fitness(sc, r["T00"], r["T10"], r["T03"], r["T13"]), rel=1e-13)
 
 
+def test_fitness_sum_at_the_chunk_boundaries(gpu, oracle):
+    """The fitness sum is built from chunks of 64 consecutive points (ndt_fitness.hip.h, round 5): scans whose lengths sit on
+    and around the chunk, the block (256) and the group-of-chunks (1024) boundaries, in one ragged batch and as hypotheses of
+    one scan (`shared_scan`: the other form of the kernels) -- against the plain per-query search and the oracle."""
+    capi, ctx = gpu
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C2"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    prm = capi.default_params(resolution=cfg["resolution"], max_iter=0)        # (the match stays at its seed: the fitness is the subject)
+    gm = capi.Map(ctx, m, prm)
+    om = oracle.Map(m, oracle.default_params(resolution=cfg["resolution"], max_iter=0))
+    lens = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4097]
+    parts, inits = [], []
+    for b, n in enumerate(lens):
+        scan, truth, init = sf.make(b)
+        sc = scan[:n].copy()
+        if n > 70:
+            sc[[3, 64]] = np.nan                                                # (points without a distance inside a chunk)
+        parts.append(sc); inits.append(init)
+    scans = np.concatenate(parts); off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+    res = gm.align_batch(scans, off, np.array(inits))
+    assert np.all(res["status"] == 0)
+    for b, sc in enumerate(parts):
+        r = res[b]
+        assert r["fitness"] == pytest.approx(gm.fitness_at(sc, r["T00"], r["T10"], r["T03"], r["T13"]), rel=1e-13), lens[b]
+        assert r["fitness"] == pytest.approx(om.fitness(sc, r["T00"], r["T10"], r["T03"], r["T13"]), rel=1e-13), lens[b]
+    for n in (65, 1025):
+        sc = parts[lens.index(n)]
+        seeds = np.array(inits[:5])
+        sh = gm.align_batch(sc, np.array([0, n], np.uint64), seeds, shared_scan=True)
+        own = gm.align_batch(np.tile(sc, (5, 1)), (np.arange(6) * n).astype(np.uint64), seeds)
+        assert sh.tobytes() == own.tobytes()
+        for b in range(5):
+            assert sh[b]["fitness"] == pytest.approx(om.fitness(sc, sh[b]["T00"], sh[b]["T10"], sh[b]["T03"], sh[b]["T13"]), rel=1e-13)
+
+
 def test_far_phase_from_the_occupancy_tiles_matches_the_ring_walk(gpu, oracle):
     """Launches whose matches share one scan (`shared_scan`: hypothesis scoring) finish the queries that are more than a
     voxel away from every map point in a kernel of their own, from the 8 x 8-voxel occupancy words of the map
