@@ -118,6 +118,7 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=1, choices=[1, 2, 3, 4], help="match launches in flight (k: k contexts / streams in turn, k + 1 map buffers)")
     ap.add_argument("--workgroups", type=int, default=0, help="workgroups per match launch (0 = one per CU); fewer leave CUs to the map build's stream")
     ap.add_argument("--max-helpers", type=int, default=-1, help="helper workgroups per unfinished scan (default -1: the library chooses, 2 for whole-GPU batches and 8 below); fewer free CUs earlier for whatever is queued behind the launch")
+    ap.add_argument("--defer-fitness", type=int, default=0, choices=[0, 1], help="NDT_OPT_DEFER_FITNESS on the match contexts (and one more map buffer): the fitness kernels of a launch on the context's own stream, beside the next launch's match kernel.  An experiment, not the headline: LOG R5.14")
     ap.add_argument("--prepare", choices=["off", "build-stream", "own-stream"], default="off",
                     help="prepare batch i ahead of its launch (ndt_align_batch_prepare_dev: optimiser start, window geometry and voxel order as a kernel of its own): behind the step's rebuild on the build stream, or on a stream of its own queued first.  Off by default: the match kernel is 18 us shorter with it (roofline.frac 0.30 -> 0.32) but the step is not -- the order kernel's 1024-thread workgroups need whole CUs and only get them when the fitness kernels of the step before are through (LOG R5.2)")
     ap.add_argument("--time-builds", action="store_true", help="extra events around the map build and around the whole launch inside the step loop (launch_interval_ms, map_build_in_step_ms)")
@@ -347,13 +348,15 @@ class Pipeline:
                 c.set_option(capi.OPT_WORKGROUPS, args.workgroups)
             if args.max_helpers >= 0:
                 c.set_option(capi.OPT_MAX_HELPERS, args.max_helpers)
+            if args.defer_fitness:
+                c.set_option(capi.OPT_DEFER_FITNESS, 1)
         self.stream, self.ctx = self.streams[0], self.mctx[0]
         torch.cuda.set_stream(self.stream)
         self.prm = capi.default_params(resolution=I.cfg["resolution"])     # PCL 1.10 preset; otherwise ndt_mapping.launch:32-36
         if args.libm_f32 is not None:
             self.prm.libm_f32 = args.libm_f32
         self.d_map = torch.from_numpy(I.map_xy).to(dev)
-        self.nbuf = k + 1
+        self.nbuf = k + 1 + (1 if args.defer_fitness else 0)     # (deferred fitness: the launch before last may still be reading its map)
         self.d_res2 = [torch.zeros(I.B * capi.RESULT_BYTES, dtype=torch.uint8, device=dev) for _ in range(self.nbuf)]
         self.side = torch.cuda.Stream(device=dev) if world > 1 else None      # gather of step i while step i + 1 computes
         self.ev_done = [torch.cuda.Event() for _ in range(self.nbuf)]

@@ -151,8 +151,18 @@ void *ndt_ctx_stream(ndt_ctx *ctx);               /* hipStream_t the context wor
  *   NDT_OPT_INJECT_FAULT k      test instrumentation for the error paths: the k-th next match launch of the context returns
  *                               NDT_E_HIP right behind the dispatch of its first kernel (0 = off, the default).  The call
  *                               leaves the context usable: the kernel that was queued is ordered in front of whatever any
- *                               stream does with the context next. */
-enum ndt_option { NDT_OPT_MAX_HELPERS = 1, NDT_OPT_WORKGROUPS = 2, NDT_OPT_INJECT_FAULT = 3 };
+ *                               stream does with the context next.
+ *   NDT_OPT_DEFER_FITNESS 0 / 1 for callers with a stream of batches (ndt_align_batch_dev only; default 0).  1: the call queues the
+ *                               match kernel on the caller's stream and the fitness kernels on a stream of the context's own
+ *                               behind it, so the caller's NEXT launch starts its match kernel at once and the fitness
+ *                               kernels fill the CUs its idle workgroups leave.  The records of a launch -- their `fitness`
+ *                               field above all -- are then complete at the LAUNCH'S END, not at the caller's stream's
+ *                               position behind the call: wait for it with ndt_ctx_wait_launch (or a device-wide
+ *                               synchronisation) before reading them, keep scans / offsets / initial guesses alive until
+ *                               then, and give two launches in a row different `out` arrays (a launch waits for the end of
+ *                               the launch before last by itself).  Every other entry point of the context waits for a
+ *                               deferred launch's end before it touches the context.  Same kernels, same records. */
+enum ndt_option { NDT_OPT_MAX_HELPERS = 1, NDT_OPT_WORKGROUPS = 2, NDT_OPT_INJECT_FAULT = 3, NDT_OPT_DEFER_FITNESS = 4 };
 int ndt_ctx_set_option(ndt_ctx *ctx, int option, long long value);
 /* Make the context work on a caller-owned hipStream_t (e.g. the stream a host framework already
  * orders its copies on); NULL restores the context's own stream. */

@@ -51,7 +51,7 @@ RESULT_DTYPE = np.dtype([
 RESULT_BYTES = RESULT_DTYPE.itemsize
 FLAG_WINDOW_SPILL, FLAG_REGION_CLIPPED, FLAG_UNSORTED = 1, 2, 4      # ndt_result.flags
 NDT_OK, NDT_E_ARG, NDT_E_HIP, NDT_E_NO_DEVICE, NDT_E_GRID, NDT_E_NOMEM = 0, -1, -2, -3, -4, -5    # ndt_status
-OPT_MAX_HELPERS, OPT_WORKGROUPS, OPT_INJECT_FAULT = 1, 2, 3            # ndt_ctx_set_option
+OPT_MAX_HELPERS, OPT_WORKGROUPS, OPT_INJECT_FAULT, OPT_DEFER_FITNESS = 1, 2, 3, 4            # ndt_ctx_set_option
 
 EXPORTS = [
     "ndt_default_params", "ndt_params_pcl110", "ndt_params_pcl18", "ndt_params_pcl_new", "ndt_ctx_create", "ndt_ctx_destroy", "ndt_last_error", "ndt_ctx_stream",

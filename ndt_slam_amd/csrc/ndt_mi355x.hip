@@ -78,10 +78,12 @@ struct ndt_ctx {
   void *d_trace = nullptr; size_t d_trace_cap = 0;
   void *d_rows = nullptr; size_t d_rows_cap = 0;
   void *d_sorted = nullptr; size_t d_sorted_cap = 0;   // cell-ordered copy of the scans
+  void *d_sorted_x[2] = {nullptr, nullptr}; size_t d_sorted_x_cap[2] = {0, 0};   // NDT_OPT_DEFER_FITNESS: the copies of the launches in between (the last ones' are still read by their fitness kernels)
   void *d_fit = nullptr; size_t d_fit_cap = 0;         // squared distance to the nearest map point, per scan point (shared_scan launches)
   void *d_fit_part = nullptr; size_t d_fit_part_cap = 0;   // FitPart per chunk of 64 scan points (ndt_fitness.hip.h)
   void *d_far = nullptr; size_t d_far_cap = 0;         // deferred far phase of the fitness search: per match two counts, then the lists
   void *d_ws = nullptr; size_t d_ws_cap = 0;           // WsHeader + ScanCtl[B] + chunk totals
+  void *d_ws_x[2] = {nullptr, nullptr}; size_t d_ws_x_cap[2] = {0, 0};       // NDT_OPT_DEFER_FITNESS: the control words of the launches in between
   void *d_pf = nullptr; size_t d_pf_cap = 0;           // pre-filter: filtered points at the raw offsets + counts
   void *d_rn = nullptr; size_t d_rn_cap = 0;           // neighbour removal: block offsets + keep flags
   void *d_mm = nullptr; size_t d_mm_cap = 0;           // local-map assembly: jobs, pieces, voxel sets, lists
@@ -112,9 +114,21 @@ struct ndt_ctx {
   // previous one first waits for the previous user (ev_scratch).
   hipEvent_t ev_scratch = nullptr; hipStream_t scratch_stream = nullptr; bool scratch_used = false, scratch_recorded = false;
   size_t ws_clean = 0;                                 // leading bytes of d_ws known to be zero (cleared by the previous launch's last kernel)
+  size_t ws_clean_x[2] = {0, 0};                       // the same of d_ws_x
   // ring of timing events of the last kTimeRing match launches: match kernel start / stop, fitness_reduce_kernel stop (attached to the dispatches)
   static constexpr int kTimeRing = 64;
   hipEvent_t ev_ring[3 * kTimeRing] = {};
+  // NDT_OPT_DEFER_FITNESS: the fitness kernels of ndt_align_batch_dev on a stream of the context's own, beside whatever the
+  // caller's stream runs next (the next launch's match kernel: its idle workgroups' CUs)
+  int defer_fitness = 0;
+  hipStream_t fit_stream = nullptr;
+  bool ring_deferred[kTimeRing] = {};                  // per launch of the ring
+  struct FitJob {                                      // the fitness kernels of one launch: what queue_fitness needs
+    MapView V; const float *scans = nullptr; const unsigned long long *offsets = nullptr; int B = 0, shared_scan = 0;
+    size_t total_points = 0; float2 *sorted = nullptr; ndt_result *out = nullptr; unsigned char *ws = nullptr;
+    size_t zero_bytes = 0, far_cnt_bytes = 0; bool sse = false; unsigned slot = 0;
+  };
+  bool deferred_pending = false;                       // the last launch's fitness kernels may still be running beside the caller's stream
   unsigned long long launches = 0;
 };
 
@@ -190,7 +204,13 @@ int ensure_t(ndt_ctx *ctx, T **p, size_t *cap_elems, size_t need_elems) {
 // (An event record is a barrier packet between kernels: a call on the context's own / registered stream -- which lives
 // as long as the registration -- records nothing; the event is recorded on that stream when a call on ANOTHER stream
 // arrives.  A call on a foreign stream records at once: the stream may be gone by the time the next call comes.)
-int scratch_begin(ndt_ctx *ctx, hipStream_t st) {
+int scratch_begin(ndt_ctx *ctx, hipStream_t st, bool deferred_launch = false) {
+  // (NDT_OPT_DEFER_FITNESS) whatever uses the context's scratch next waits for the fitness kernels still running on the
+  // context's own stream -- except the next deferred launch, which orders itself (launch_align)
+  if (ctx->deferred_pending && !deferred_launch && ctx->launches > 0) {
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_ring[3 * ((ctx->launches - 1) % ndt_ctx::kTimeRing) + 2], 0));
+    ctx->deferred_pending = false;
+  }
   if (ctx->scratch_used && st != ctx->scratch_stream) {
     if (!ctx->scratch_recorded) HIP_TRY(ctx, hipEventRecord(ctx->ev_scratch, ctx->scratch_stream));
     HIP_TRY(ctx, hipStreamWaitEvent(st, ctx->ev_scratch, 0));
@@ -261,27 +281,91 @@ int grid_for(size_t n, int block, int cap = 2048) {
   return (int)g;
 }
 
+// The fitness kernels of one launch on stream fs (behind its match kernel there: stream order, or the caller has made fs wait).
+int queue_fitness(ndt_ctx *ctx, const ndt_ctx::FitJob &J, hipStream_t fs) {
+  const MapView &V = J.V;
+  const float *scans = J.scans; const unsigned long long *offsets = J.offsets;
+  const int B = J.B, shared_scan = J.shared_scan; const size_t total_points = J.total_points;
+  float2 *sorted = J.sorted; ndt_result *out = J.out; unsigned char *ws = J.ws;
+  const size_t zero_bytes = J.zero_bytes, far_cnt_bytes = J.far_cnt_bytes; const bool sse = J.sse;
+  hipEvent_t *evr = ctx->ev_ring + 3 * J.slot;
+  float *fit = (float *)ctx->d_fit;
+  FitPart *parts = (FitPart *)ctx->d_fit_part;
+  {
+    const size_t avg = shared_scan ? total_points : (total_points + (size_t)B - 1) / (size_t)B;
+    const unsigned gx = (unsigned)std::min<size_t>(64, std::max<size_t>(1, (avg + 255) / 256));
+    // one-dimensional, XCD-aware: workgroup w -> (match, block of the match) in fit_block_of (ndt_fitness.hip.h)
+    const dim3 grid(gx * (unsigned)(((size_t)B + 7) / 8 * 8));
+    if (shared_scan) {
+      // hypothesis scoring: most seeds end far from the map -- the far phase of the search as a pass of its own over the
+      // queries that need it (ndt_fitness.hip.h)
+      const size_t cnt_bytes = far_cnt_bytes;
+      unsigned *far_n = (unsigned *)ctx->d_far, *far_idx = (unsigned *)((unsigned char *)ctx->d_far + cnt_bytes);
+      { hipError_t e = hipMemsetAsync(far_n, 0, cnt_bytes, fs); if (e != hipSuccess) return fail(ctx, NDT_E_HIP, std::string("queue_fitness: hipMemsetAsync: ") + hipGetErrorString(e)); }
+      if (sse) fitness_points_kernel<true, true><<<grid, 256, 0, fs>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx, nullptr);
+      else     fitness_points_kernel<false, true><<<grid, 256, 0, fs>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx, nullptr);
+      if (sse) fitness_far_kernel<true><<<grid, 256, 0, fs>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
+      else     fitness_far_kernel<false><<<grid, 256, 0, fs>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
+      hipExtLaunchKernelGGL(fitness_reduce_kernel<true>, dim3(std::min(B, 4 * ctx->num_cus)), dim3(kFitBlock), 0, fs, nullptr, evr[2], 0,
+                            offsets, B, shared_scan, (const float *)fit, out, parts, (uint4 *)ws, (unsigned)(zero_bytes / 16));
+    } else {
+      // scans of their own: the search kernel leaves a {sum, count} per chunk of 64 points instead of a distance per point
+      if (sse) fitness_points_kernel<true, false><<<grid, 256, 0, fs>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr, (int)gx, parts);
+      else     fitness_points_kernel<false, false><<<grid, 256, 0, fs>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr, (int)gx, parts);
+      // (a wave per match; at least as many workgroups as clear the control words with one store per thread, a CU each at most)
+      const size_t close_wgs = std::max<size_t>(((size_t)B + kFitBlock / 64 - 1) / (kFitBlock / 64),
+                                                std::min<size_t>((size_t)ctx->num_cus, (zero_bytes / 16 + kFitBlock - 1) / kFitBlock));
+      hipExtLaunchKernelGGL(fitness_reduce_kernel<false>, dim3((unsigned)close_wgs), dim3(kFitBlock), 0, fs, nullptr, evr[2], 0,
+                            offsets, B, shared_scan, (const float *)nullptr, out, parts, (uint4 *)ws, (unsigned)(zero_bytes / 16));
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(ctx, NDT_E_HIP, std::string("queue_fitness: ") + hipGetErrorString(e));
+  return NDT_OK;
+}
+
+#ifndef NDT_DEFER_SETS
+#define NDT_DEFER_SETS 2
+#endif
+constexpr int kDeferSets = NDT_DEFER_SETS;      // NDT_OPT_DEFER_FITNESS: launches whose fitness kernels may be outstanding behind a new launch's match kernel, + 1
+static_assert(kDeferSets >= 2 && kDeferSets <= 3, "two spare sets of control words and ordered copies");
 int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *scans,
                  const unsigned long long *offsets, int B, int shared_scan, size_t total_points, const double *inits,
                  ndt_result *out, double *trace, int trace_cap, int *trace_rows, unsigned long long *prof,
-                 ndt_ctx::PrepSet *pset = nullptr) {
+                 ndt_ctx::PrepSet *pset = nullptr, bool defer = false) {
   const bool sse = map->prm.transform_sse != 0, incl = map->prm.radius_inclusive != 0;
+  // NDT_OPT_DEFER_FITNESS: launches take turns on two sets of control words and ordered copies -- the fitness kernels of
+  // launch i (the context's own stream) read set i & 1 while the match kernel of launch i + 1 (the caller's stream) fills the other
+  const int set = defer ? (int)(ctx->launches % (unsigned long long)kDeferSets) : 0;      // (0: the buffers every other entry point uses)
+  void **p_ws = set ? &ctx->d_ws_x[set - 1] : &ctx->d_ws; size_t *p_ws_cap = set ? &ctx->d_ws_x_cap[set - 1] : &ctx->d_ws_cap;
+  size_t *p_clean = set ? &ctx->ws_clean_x[set - 1] : &ctx->ws_clean;
+  void **p_sorted = set ? &ctx->d_sorted_x[set - 1] : &ctx->d_sorted; size_t *p_sorted_cap = set ? &ctx->d_sorted_x_cap[set - 1] : &ctx->d_sorted_cap;
+  {
+    const unsigned long long L = ctx->launches;
+    auto end_of = [&](unsigned long long k) { return ctx->ev_ring[3 * (k % ndt_ctx::kTimeRing) + 2]; };
+    // leaving the deferred mode: behind the last launch's fitness kernels; in it: behind those of the launch before last (whose
+    // control words, ordered copies -- and, the caller alternating two of them, result records -- this launch takes over)
+    if (!defer && L >= 1 && ctx->ring_deferred[(L - 1) % ndt_ctx::kTimeRing]) HIP_TRY(ctx, hipStreamWaitEvent(st, end_of(L - 1), 0));   // (the fitness stream is in order: the last launch's end is everybody's)
+    if (defer && L >= (unsigned long long)kDeferSets && ctx->ring_deferred[(L - kDeferSets) % ndt_ctx::kTimeRing]) HIP_TRY(ctx, hipStreamWaitEvent(st, end_of(L - kDeferSets), 0));
+    // (the caller's priority class: below it these kernels starve behind every match kernel -- 0.49 against 0.37 ms per bench step)
+    if (defer && !ctx->fit_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->fit_stream, hipStreamNonBlocking));
+  }
   const MapView &V = map->view;
   const OptParams O = opt_of(map->prm);
   // workspace: header + one control line per scan (zeroed every launch) + chunk totals
   // control words, epoch-tagged pose halves and unit totals (zero at kernel start), then the marked-cell bitmaps
   const size_t zero_bytes = sizeof(WsHeader) + (size_t)B * sizeof(ScanCtl) + (size_t)B * kUnits * kUnitWords * sizeof(u64);
   const size_t ws_bytes = zero_bytes + (size_t)B * (kRegionCells / 8);
-  const size_t ws_cap_before = ctx->d_ws_cap;
-  int rc = ensure(ctx, &ctx->d_ws, &ctx->d_ws_cap, ws_bytes);
+  const size_t ws_cap_before = *p_ws_cap;
+  int rc = ensure(ctx, p_ws, p_ws_cap, ws_bytes);
   if (rc) return rc;
-  if (ctx->d_ws_cap != ws_cap_before) ctx->ws_clean = 0;       // a new allocation
+  if (*p_ws_cap != ws_cap_before) *p_clean = 0;                // a new allocation
   // ordered copy of every scan (what the passes and the fitness kernel read) and one float per point for the
   // fitness score; when every match uses scan 0 each match has its own slot of the scan's size
   const size_t slots = (shared_scan ? (size_t)B : (size_t)1) * total_points;
-  if ((rc = ensure(ctx, &ctx->d_sorted, &ctx->d_sorted_cap, slots * sizeof(float2) + 16))) return rc;
+  if ((rc = ensure(ctx, p_sorted, p_sorted_cap, slots * sizeof(float2) + 16))) return rc;
   if (shared_scan && (rc = ensure(ctx, &ctx->d_fit, &ctx->d_fit_cap, slots * sizeof(float) + 16))) return rc;   // (scans of their own: chunk sums only, d_fit_part)
-  float2 *sorted = pset ? (float2 *)pset->sorted : (float2 *)ctx->d_sorted;      // (a prepared batch: its ordered copies are in its own set)
+  float2 *sorted = pset ? (float2 *)pset->sorted : (float2 *)*p_sorted;      // (a prepared batch: its ordered copies are in its own set)
   const PrepRec *prep = pset ? (const PrepRec *)pset->recs : nullptr;
   const unsigned *prep_map = pset ? (const unsigned *)pset->maps : nullptr;
   float *fit = (float *)ctx->d_fit;
@@ -293,9 +377,9 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   FitPart *parts = (FitPart *)ctx->d_fit_part;
   // control words: zero before every launch -- by the last kernel of the previous launch of this context
   // (fitness_reduce_kernel), or by a memset when that did not cover enough
-  if (ctx->ws_clean < zero_bytes) HIP_TRY(ctx, hipMemsetAsync(ctx->d_ws, 0, zero_bytes, st));
-  ctx->ws_clean = 0;
-  unsigned char *ws = (unsigned char *)ctx->d_ws;
+  if (*p_clean < zero_bytes) HIP_TRY(ctx, hipMemsetAsync(*p_ws, 0, zero_bytes, st));
+  *p_clean = 0;
+  unsigned char *ws = (unsigned char *)*p_ws;
   // helper limit: 8 while a launch has fewer scans than workgroups (one scan at a time: everybody helps), 2 for whole-GPU
   // batches -- there the match kernel is as fast with 2 as with 15, and workgroups that find nothing to join leave their
   // CUs to the next step's map build earlier (round 4, after the repeated line-search passes went: LOG R4.9)
@@ -308,6 +392,7 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   hipEvent_t *evr = ctx->ev_ring + 3 * (ctx->launches % ndt_ctx::kTimeRing);
   // (the pair check left out where it cannot fire -- accumulate_pair -- in the preset's own instantiation only)
   const bool chk = !(V.e_hi > 1.0 + 1e-6);
+  ctx->ring_deferred[ctx->launches % ndt_ctx::kTimeRing] = defer;
 #define NDT_LAUNCH(S_, I_, C_)                                                                                          \
   hipExtLaunchKernelGGL((ndt_align_kernel<S_, I_, C_>), dim3(grid), dim3(kBlock), 0, st, evr[0], evr[1], 0, V, O, scans, \
                         offsets, B, shared_scan, inits, out, trace, trace_cap, trace_rows, sorted, ws, helpers, prof, prep, prep_map)
@@ -335,40 +420,29 @@ int launch_align(ndt_ctx *ctx, const ndt_map *map, hipStream_t st, const float *
   };
   if (ctx->inject_fault > 0 && --ctx->inject_fault == 0)      // NDT_OPT_INJECT_FAULT (tests): fail with the match kernel queued
     return entered(fail(ctx, NDT_E_HIP, "launch_align: injected fault behind the match kernel's dispatch (NDT_OPT_INJECT_FAULT)"));
-  // a7: fitness scores, behind the matches on the same stream
+  // a7: fitness scores, behind the matches: on the same stream, or (NDT_OPT_DEFER_FITNESS) on the context's own stream behind the
+  // match kernel's event -- the caller's stream is free for the next launch's match kernel, whose idle workgroups' CUs these
+  // kernels then fill
+  hipStream_t fs = st;
+  if (defer) {
+    fs = ctx->fit_stream;
+    hipError_t e = hipStreamWaitEvent(fs, evr[1], 0);
+    if (e != hipSuccess) return entered(fail(ctx, NDT_E_HIP, std::string("launch_align: hipStreamWaitEvent: ") + hipGetErrorString(e)));
+  }
   {
-    const size_t avg = shared_scan ? total_points : (total_points + (size_t)B - 1) / (size_t)B;
-    const unsigned gx = (unsigned)std::min<size_t>(64, std::max<size_t>(1, (avg + 255) / 256));
-    // one-dimensional, XCD-aware: workgroup w -> (match, block of the match) in fit_block_of (ndt_fitness.hip.h)
-    const dim3 grid(gx * (unsigned)(((size_t)B + 7) / 8 * 8));
-    if (shared_scan) {
-      // hypothesis scoring: most seeds end far from the map -- the far phase of the search as a pass of its own over the
-      // queries that need it (ndt_fitness.hip.h)
-      const size_t cnt_bytes = far_cnt_bytes;
-      unsigned *far_n = (unsigned *)ctx->d_far, *far_idx = (unsigned *)((unsigned char *)ctx->d_far + cnt_bytes);
-      { hipError_t e = hipMemsetAsync(far_n, 0, cnt_bytes, st); if (e != hipSuccess) return entered(fail(ctx, NDT_E_HIP, std::string("launch_align: hipMemsetAsync: ") + hipGetErrorString(e))); }
-      if (sse) fitness_points_kernel<true, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx, nullptr);
-      else     fitness_points_kernel<false, true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx, nullptr);
-      if (sse) fitness_far_kernel<true><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
-      else     fitness_far_kernel<false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, far_idx, far_n, (int)gx);
-      hipExtLaunchKernelGGL(fitness_reduce_kernel<true>, dim3(std::min(B, 4 * ctx->num_cus)), dim3(kFitBlock), 0, st, nullptr, evr[2], 0,
-                            offsets, B, shared_scan, (const float *)fit, out, parts, (uint4 *)ws, (unsigned)(zero_bytes / 16));
-    } else {
-      // scans of their own: the search kernel leaves a {sum, count} per chunk of 64 points instead of a distance per point
-      if (sse) fitness_points_kernel<true, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr, (int)gx, parts);
-      else     fitness_points_kernel<false, false><<<grid, 256, 0, st>>>(V, scans, offsets, B, shared_scan, sorted, out, fit, nullptr, nullptr, (int)gx, parts);
-      // (a wave per match; at least as many workgroups as clear the control words with one store per thread, a CU each at most)
-      const size_t close_wgs = std::max<size_t>(((size_t)B + kFitBlock / 64 - 1) / (kFitBlock / 64),
-                                                std::min<size_t>((size_t)ctx->num_cus, (zero_bytes / 16 + kFitBlock - 1) / kFitBlock));
-      hipExtLaunchKernelGGL(fitness_reduce_kernel<false>, dim3((unsigned)close_wgs), dim3(kFitBlock), 0, st, nullptr, evr[2], 0,
-                            offsets, B, shared_scan, (const float *)nullptr, out, parts, (uint4 *)ws, (unsigned)(zero_bytes / 16));
-    }
+    ndt_ctx::FitJob J;
+    J.V = V; J.scans = scans; J.offsets = offsets; J.B = B; J.shared_scan = shared_scan; J.total_points = total_points;
+    J.sorted = sorted; J.out = out; J.ws = ws; J.zero_bytes = zero_bytes; J.far_cnt_bytes = far_cnt_bytes; J.sse = sse;
+    J.slot = (unsigned)(ctx->launches % ndt_ctx::kTimeRing);
+    int qrc = queue_fitness(ctx, J, fs);
+    if (qrc != NDT_OK) return entered(qrc);
   }
   {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return entered(fail(ctx, NDT_E_HIP, std::string("launch_align: ") + hipGetErrorString(e)));
   }
-  ctx->ws_clean = zero_bytes;
+  *p_clean = zero_bytes;
+  if (defer) ctx->deferred_pending = true;
   return entered(NDT_OK);
 }
 
@@ -475,6 +549,9 @@ int ndt_ctx_set_option(ndt_ctx *c, int option, long long value) {
     case NDT_OPT_INJECT_FAULT:
       if (value < 0 || value > 1000000) return fail(c, NDT_E_ARG, "NDT_OPT_INJECT_FAULT: 0 (off) or the number of the launch that fails");
       c->inject_fault = (int)value; return NDT_OK;
+    case NDT_OPT_DEFER_FITNESS:
+      if (value != 0 && value != 1) return fail(c, NDT_E_ARG, "NDT_OPT_DEFER_FITNESS: 0 or 1");
+      c->defer_fitness = (int)value; return NDT_OK;
     default: return fail(c, NDT_E_ARG, "ndt_ctx_set_option: unknown option");
   }
 }
@@ -485,6 +562,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
   hipError_t e;
   e = hipSetDevice(c->device);
   if (c->stream) e = hipStreamSynchronize(c->stream);
+  if (c->fit_stream) { e = hipStreamSynchronize(c->fit_stream); e = hipStreamDestroy(c->fit_stream); }
   if (c->own_stream) e = hipStreamDestroy(c->own_stream);
   if (c->ev0) e = hipEventDestroy(c->ev0);
   if (c->ev1) e = hipEventDestroy(c->ev1);
@@ -507,7 +585,7 @@ int ndt_ctx_destroy(ndt_ctx *c) {
     if (S.maps) e = hipFree(S.maps);
   }
   if (c->h_mm) e = hipHostFree(c->h_mm);
-  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_fit, c->d_far, c->d_fit_part, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
+  void *bufs[] = {c->d_scan, c->d_off, c->d_init, c->d_res, c->d_tmp, c->d_trace, c->d_rows, c->d_sorted, c->d_sorted_x[0], c->d_sorted_x[1], c->d_ws_x[0], c->d_ws_x[1], c->d_fit, c->d_far, c->d_fit_part, c->d_ws, c->d_pf, c->d_rn, c->d_mm};
   for (void *b : bufs) if (b) e = hipFree(b);
   (void)e;
   delete c;
@@ -980,10 +1058,11 @@ int ndt_align_batch_dev(ndt_ctx *ctx, const ndt_map *map, const float *scans, co
     pset->valid = false;                           // one launch per prepared set (the caller prepares the next batch)
   }
   int rc;
-  if ((rc = scratch_begin(ctx, st))) return rc;
+  const bool defer = ctx->defer_fitness != 0;
+  if ((rc = scratch_begin(ctx, st, defer))) return rc;
   ScratchScope scope(ctx, st);
   if ((rc = launch_align(ctx, map, st, scans, (const unsigned long long *)offsets, B, shared_scan, total_points, inits,
-                         out, nullptr, 0, nullptr, nullptr, pset)))
+                         out, nullptr, 0, nullptr, nullptr, pset, defer)))
     return rc;                                     // (scope: scratch_end all the same -- kernels may have been queued)
   return scope.close();
 }

@@ -962,6 +962,72 @@ def test_wait_launch_orders_another_stream_behind_a_launch(gpu):
         cx.wait_launch(10)                                     # ten launches were made: 0 .. 9 exist
 
 
+def test_deferred_fitness_gives_the_same_records(gpu):
+    """NDT_OPT_DEFER_FITNESS: the fitness kernels of a launch on the context's own stream, beside whatever the caller's stream
+    runs next.  A stream of launches with alternating result arrays and two batches that take turns -- a whole-GPU one and a
+    ragged one with an empty scan --, read at the launches' ends (ndt_ctx_wait_launch), equals the same stream without the option
+    byte for byte; the caller's stream alone does NOT cover a deferred launch's fitness; entry points that are not deferred
+    launches (a host-pointer match, a launch after the option is switched off) wait for the deferred work by themselves."""
+    import torch
+    capi, _ = gpu
+    from ndt_slam_amd import synth
+    cfg = synth.CONFIGS["C3"]
+    m = synth.make_map(cfg["n_map"], cfg["half"])
+    sf = synth.ScanFactory(m, cfg["half"], cfg["n_scan"])
+    prm = capi.default_params(resolution=cfg["resolution"])
+    dev = torch.device("cuda", 0)
+    scans, off, truths, inits = sf.batch(0, 256)
+    parts = [scans[int(off[b]):int(off[b + 1])][:(0 if b == 5 else 1 + (b * 977) % 10000)] for b in range(40)]
+    r_off = np.concatenate([[0], np.cumsum([len(p) for p in parts])]).astype(np.uint64)
+    r_scans = np.concatenate(parts)
+    batches = []
+    for sc, of, ini in ((scans, off, inits), (r_scans, r_off, inits[:40])):
+        batches.append((torch.from_numpy(sc).to(dev), torch.from_numpy(of.astype(np.int64)).to(dev), torch.from_numpy(ini).to(dev), len(ini), len(sc)))
+
+    def stream_of_launches(defer):
+        ctx = capi.Context(0)
+        st = torch.cuda.Stream(device=dev)
+        ctx.set_stream(st.cuda_stream)
+        if defer:
+            ctx.set_option(capi.OPT_DEFER_FITNESS, 1)
+        gm = capi.Map(ctx, m, prm)
+        outs = [[torch.zeros(b[3] * capi.RESULT_BYTES, dtype=torch.uint8, device=dev) for _ in range(2)] for b in batches]
+        got = []
+        order = [0, 0, 1, 0, 1, 1, 0, 0]
+        for i, w in enumerate(order):
+            d_sc, d_of, d_in, B, npts = batches[w]
+            gm.align_batch_dev(d_sc.data_ptr(), d_of.data_ptr(), B, npts, d_in.data_ptr(), outs[w][i % 2].data_ptr(), stream=st.cuda_stream, ctx=ctx)
+            if i == 3 and defer:
+                st.synchronize()                                   # the caller's stream: the match kernel's part of the records only
+                early = np.frombuffer(outs[w][i % 2].cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE)
+                ctx.wait_launch(0, st.cuda_stream)
+            else:
+                ctx.wait_launch(0, st.cuda_stream)                 # the launch's end
+            st.synchronize()
+            got.append(np.frombuffer(outs[w][i % 2].cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE).copy())
+            if i == 3 and defer:
+                assert np.array_equal(early["T00"], got[-1]["T00"]) and np.array_equal(early["iters"], got[-1]["iters"])
+        # not a deferred launch: waits for what is deferred by itself
+        d_sc, d_of, d_in, B, npts = batches[0]
+        gm.align_batch_dev(d_sc.data_ptr(), d_of.data_ptr(), B, npts, d_in.data_ptr(), outs[0][0].data_ptr(), stream=st.cuda_stream, ctx=ctx)
+        one = gm.align(parts[0], inits[0])                         # (host pointers, synchronous)
+        if defer:
+            ctx.set_option(capi.OPT_DEFER_FITNESS, 0)
+        gm.align_batch_dev(d_sc.data_ptr(), d_of.data_ptr(), B, npts, d_in.data_ptr(), outs[0][1].data_ptr(), stream=st.cuda_stream, ctx=ctx)
+        st.synchronize()                                           # (not deferred: the stream's order covers it -- and the launch before it)
+        tail = [np.frombuffer(o.cpu().numpy().tobytes(), dtype=capi.RESULT_DTYPE).copy() for o in outs[0]]
+        return got, one, tail
+
+    plain, one_p, tail_p = stream_of_launches(False)
+    deferred, one_d, tail_d = stream_of_launches(True)
+    assert np.all(plain[0]["status"] == 0) and np.all(plain[0]["fitness"] < 1e30)
+    for a, b in zip(plain, deferred):
+        assert a.tobytes() == b.tobytes()
+    assert one_p.tobytes() == one_d.tobytes()
+    for a, b in zip(tail_p, tail_d):
+        assert a.tobytes() == b.tobytes() and a.tobytes() == plain[0].tobytes()
+
+
 def test_a_batch_prepared_ahead_gives_the_same_records(gpu, c1_world):
     """ndt_align_batch_prepare_dev (round 5): optimiser start, window geometry and voxel order of a batch as a kernel of its own,
     ahead of the launch.  Byte-identical records with and without it -- ragged batch with an empty scan and a scan beyond the
